@@ -1,0 +1,222 @@
+"""ctypes front end of the CPU oracle (oracle/ddc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py, never by the shipped package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libddc_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ddc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        L = _lib
+        L.orc_init.restype = None
+        for name in ("orc_rx_front_sizeof", "orc_rx_ciccomp_sizeof", "orc_rx_hilb_sizeof",
+                     "orc_delay_sizeof", "orc_rx_chain_sizeof", "orc_tx_chain_sizeof"):
+            if hasattr(L, name):
+                getattr(L, name).restype = C.c_size_t
+        L.orc_rx_front_run.restype = C.c_size_t
+        L.orc_rx_ciccomp_run.restype = C.c_size_t
+        L.orc_rx_ciccomp_cycle.restype = C.c_size_t
+        L.orc_rx_hilb_run.restype = C.c_size_t
+        L.orc_rx_hilb_cycle.restype = C.c_size_t
+        L.orc_delay_run.restype = C.c_size_t
+        L.orc_rx_chain_run.restype = C.c_size_t
+        L.orc_phrase_from_freq.restype = C.c_uint32
+        L.orc_freq_from_phrase.restype = C.c_uint32
+        L.orc_init()
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+def nco_tables():
+    t = [np.zeros(2048, np.int16) for _ in range(4)]
+    lib().orc_nco_tables(*[_p(x) for x in t])
+    return t  # sc, cc, sf, cf
+
+
+def nco_eval(acc):
+    s, c = C.c_int(), C.c_int()
+    lib().orc_nco_eval(C.c_uint32(int(acc)), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+class _State:
+    _size = None
+    _reset = None
+
+    def __init__(self, *args):
+        L = lib()
+        self.buf = C.create_string_buffer(getattr(L, self._size)())
+        getattr(L, self._reset)(self.buf, *args)
+
+
+class RxFront(_State):
+    """mixer.v + rx_mixer_shift.v + rx_cic.vhd, clock-edge model, I and Q."""
+    _size, _reset = "orc_rx_front_sizeof", "orc_rx_front_reset"
+
+    def __init__(self, phi):
+        super().__init__(C.c_uint32(int(phi)))
+
+    def tune(self, phi):
+        lib().orc_rx_front_tune(self.buf, C.c_uint32(int(phi)))
+
+    def run(self, adc):
+        adc = _i16(adc)
+        n = adc.size
+        oi = np.zeros(n // 512 + 2, np.int16)
+        oq = np.zeros(n // 512 + 2, np.int16)
+        k = lib().orc_rx_front_run(self.buf, _p(adc), C.c_size_t(n), _p(oi), _p(oq))
+        return oi[:k].copy(), oq[:k].copy()
+
+
+class RxCicComp(_State):
+    _size, _reset = "orc_rx_ciccomp_sizeof", "orc_rx_ciccomp_reset"
+
+    def run(self, x):
+        x = _i16(x)
+        out = np.zeros(x.size // 2 + 2, np.int16)
+        k = lib().orc_rx_ciccomp_run(self.buf, _p(x), C.c_size_t(x.size), _p(out))
+        return out[:k].copy()
+
+
+def rx_ciccomp_cycle(x):
+    x = _i16(x)
+    out = np.zeros(x.size // 2 + 2, np.int16)
+    k = lib().orc_rx_ciccomp_cycle(_p(x), C.c_size_t(x.size), _p(out), C.c_size_t(out.size))
+    return out[:min(k, out.size)].copy()
+
+
+class RxHilb(_State):
+    _size, _reset = "orc_rx_hilb_sizeof", "orc_rx_hilb_reset"
+
+    def run(self, x):
+        x = _i16(x)
+        out = np.zeros(x.size, np.int16)
+        lib().orc_rx_hilb_run(self.buf, _p(x), C.c_size_t(x.size), _p(out))
+        return out
+
+
+def rx_hilb_cycle(x):
+    x = _i16(x)
+    out = np.zeros(x.size + 2, np.int16)
+    k = lib().orc_rx_hilb_cycle(_p(x), C.c_size_t(x.size), _p(out), C.c_size_t(out.size))
+    return out[:min(k, out.size)].copy()
+
+
+class Delay130(_State):
+    _size, _reset = "orc_delay_sizeof", "orc_delay_reset"
+
+    def run(self, x):
+        x = _i16(x)
+        out = np.zeros(x.size, np.int16)
+        lib().orc_delay_run(self.buf, _p(x), C.c_size_t(x.size), _p(out))
+        return out
+
+
+class RxChain(_State):
+    """Whole FPGA RX side for one channel: ADC words -> SPEC/VOICE I/Q."""
+    _size, _reset = "orc_rx_chain_sizeof", "orc_rx_chain_reset"
+
+    def __init__(self, phi):
+        super().__init__(C.c_uint32(int(phi)))
+
+    def tune(self, phi):
+        lib().orc_rx_chain_tune(self.buf, C.c_uint32(int(phi)))
+
+    def run(self, adc, want_cic=False):
+        adc = _i16(adc)
+        n = adc.size
+        assert n % 1024 == 0
+        nf = n // 1024
+        spec = np.zeros((nf, 2), np.int16)
+        voice = np.zeros((nf, 2), np.int16)
+        cic = np.zeros((2 * nf, 2), np.int16) if want_cic else None
+        k = lib().orc_rx_chain_run(self.buf, _p(adc), C.c_size_t(n), _p(spec), _p(voice),
+                                   _p(cic) if want_cic else None)
+        assert k == nf
+        return (spec, voice, cic) if want_cic else (spec, voice)
+
+
+def rx_chain_packed(packed, row_bytes, n_channels, n, phi):
+    """Fresh-state RX chain over packed 12-bit rows; returns spec, voice [ch][frame][2]."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    phi = np.ascontiguousarray(phi, dtype=np.uint32)
+    nf = n // 1024
+    spec = np.zeros((n_channels, nf, 2), np.int16)
+    voice = np.zeros((n_channels, nf, 2), np.int16)
+    lib().orc_rx_chain_packed(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_channels),
+                              C.c_size_t(n), _p(phi), _p(spec), _p(voice))
+    return spec, voice
+
+
+def pack12(x):
+    x = _i16(x)
+    out = np.zeros((x.size + 1) // 2 * 3, np.uint8)
+    lib().orc_pack12(_p(x), C.c_size_t(x.size), _p(out))
+    return out
+
+
+def unpack12(packed, n):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    out = np.zeros(n, np.int16)
+    lib().orc_unpack12(_p(packed), C.c_size_t(n), _p(out))
+    return out
+
+
+def phrase_from_freq(freq, adc_clock=49152000):
+    sw = C.c_int()
+    v = lib().orc_phrase_from_freq(C.c_uint32(int(freq)), C.c_uint32(int(adc_clock)), C.byref(sw))
+    return int(v), bool(sw.value)
+
+
+def freq_from_phrase(phrase, adc_clock=49152000):
+    return int(lib().orc_freq_from_phrase(C.c_uint32(int(phrase)), C.c_uint32(int(adc_clock))))
+
+
+def pack_rx_frame(spec_i, spec_q, voice_i, voice_q):
+    out = (C.c_uint8 * 8)()
+    lib().orc_pack_rx_frame(C.c_int16(spec_i), C.c_int16(spec_q), C.c_int16(voice_i),
+                            C.c_int16(voice_q), out)
+    return bytes(out)
+
+
+def unpack_tx_frame(b):
+    buf = (C.c_uint8 * 4)(*b)
+    i, q = C.c_int16(), C.c_int16()
+    lib().orc_unpack_tx_frame(buf, C.byref(i), C.byref(q))
+    return i.value, q.value
+
+
+def parse_params(b):
+    buf = (C.c_uint8 * 4)(*b)
+    tx, pre, f = C.c_int(), C.c_int(), C.c_uint32()
+    lib().orc_parse_params(buf, C.byref(tx), C.byref(pre), C.byref(f))
+    return tx.value, pre.value, f.value
