@@ -1,0 +1,114 @@
+/*
+ * ua3reo_ddc.h -- C ABI of the MI355X DDC/DUC signal chain.
+ *
+ * One ddc_ctx owns the per-channel state of N independent tuned channels on one
+ * GPU: NCO phase, CIC window moments, FIR delay lines.  Every entry point
+ * returns 0 on success or a negative errno-style code; ddc_last_error() gives
+ * the text.  A ctx is single-owner (not thread-safe) and runs on one HIP
+ * stream; the *_dev calls are asynchronous on that stream, the host-pointer
+ * calls return when the results are in the caller's buffers.
+ *
+ * The reference has no FFI layer: its boundary is the FPGA<->MCU byte contract
+ * (FPGA/stm32_interface.v) and the global-buffer C functions of STM32/Src.
+ * Each declaration below names the reference interface it stands in for.
+ */
+#ifndef UA3REO_DDC_H
+#define UA3REO_DDC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDC_ADC_CLOCK_DEFAULT 49152000u /* STM32/Src/settings.h:10 ADCDAC_CLOCK */
+#define DDC_DECIMATION 1024u            /* rx_cic 512 x rx_ciccomp 2 */
+#define DDC_TX_INTERPOLATION 1024u      /* tx_ciccomp 2 x tx_cic 512 */
+
+typedef struct ddc_ctx ddc_ctx;
+
+typedef struct ddc_config {
+    uint32_t n_channels; /* independent tuned channels held by this ctx */
+    uint32_t fs_adc;     /* ADC/DAC clock in Hz; 0 = DDC_ADC_CLOCK_DEFAULT */
+    int32_t device;      /* HIP device ordinal */
+    uint32_t reserved;
+} ddc_config;
+
+/* Library / device life cycle.  Replaces FPGA_Init (STM32/Src/fpga.c:29-55):
+ * allocates the per-channel state in HBM, zeroed as the FPGA is after reset. */
+int ddc_create(const ddc_config *cfg, ddc_ctx **out);
+void ddc_destroy(ddc_ctx *ctx);
+const char *ddc_last_error(const ddc_ctx *ctx);
+const char *ddc_version(void);
+
+/* Tuning.  ddc_tune writes the 22-bit phase increment the way command 1 of the
+ * bus does (FPGA/stm32_interface.v:157-171 -> NCO phi_inc_i).  ddc_tune_hz is
+ * getPhraseFromFrequency (STM32/Src/functions.c:206-226): folds the frequency
+ * into the first Nyquist zone and reports TRX_IQ_swap through *iq_swap.
+ * channel = -1 applies to all channels. */
+int ddc_tune(ddc_ctx *ctx, int32_t channel, uint32_t phi_inc22);
+int ddc_tune_hz(ddc_ctx *ctx, int32_t channel, uint32_t freq_hz, int *iq_swap);
+/* One 22-bit word per channel in one transfer (n must equal n_channels). */
+int ddc_tune_many(ddc_ctx *ctx, const uint32_t *phi_inc22, uint32_t n);
+uint32_t ddc_phrase_from_frequency(uint32_t freq_hz, uint32_t fs_adc, int *iq_swap);
+uint32_t ddc_frequency_from_phrase(uint32_t phrase, uint32_t fs_adc); /* functions.c:199-204 */
+
+/* Zero one channel's (or, with -1, every channel's) RX datapath state the
+ * way the FPGA's reset = RX_N does on every TX->RX switch
+ * (FPGA/UA3REO.bdf clk_enable/reset wiring); the tuning word is kept. */
+int ddc_rx_reset(ddc_ctx *ctx, int32_t channel);
+/* Direct access to the NCO phase accumulator (22 bit) for state save/restore. */
+int ddc_rx_set_phase(ddc_ctx *ctx, int32_t channel, uint32_t phase22);
+int ddc_rx_get_phase(ddc_ctx *ctx, int32_t channel, uint32_t *phase22);
+
+/* RX: ADC words -> SPEC and VOICE I/Q at fs/1024.
+ * Replaces the FPGA RX datapath nco + mixer.v + rx_cic.vhd + rx_ciccomp.vhd +
+ * rx_hilb.vhd + data_delay.v as wired in FPGA/UA3REO.bdf, i.e. what command 4
+ * of the bus (FPGA/stm32_interface.v:228-271) hands to
+ * FPGA_fpgadata_getiq (STM32/Src/fpga.c:286-401) once per 48 kHz tick.
+ *
+ *   adc12          packed signed 12-bit words, two per three bytes (b0=s0[7:0],
+ *                  b1=s0[11:8]|s1[3:0]<<4, b2=s1[11:4]); one row per channel,
+ *                  rows row_bytes apart (row_bytes a multiple of 16)
+ *   samples        ADC samples per channel in this call, a multiple of 1024
+ *   spec_iq        [channel][samples/1024][2] int16: SPEC_I, SPEC_Q
+ *   voice_iq       [channel][samples/1024][2] int16: VOICE_I, VOICE_Q
+ * State carries over from call to call exactly as if the samples had been
+ * clocked through in one piece.  _dev takes device pointers and queues the work
+ * on the ctx stream; the plain form takes host pointers and waits. */
+int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                       int16_t *spec_iq, int16_t *voice_iq);
+int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                   int16_t *spec_iq, int16_t *voice_iq);
+/* Debug tap: the raw rx_cic outputs of the last ddc_rx_process* call,
+ * [channel][samples/512][2] int16 (host pointer). */
+int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples);
+
+/* Wait for everything queued on the ctx stream. */
+int ddc_sync(ddc_ctx *ctx);
+/* The HIP stream of the ctx (a hipStream_t), for callers that time or chain work. */
+void *ddc_stream(ddc_ctx *ctx);
+
+/* Bus frames, byte-identical to the FPGA side of FPGA/stm32_interface.v.
+ * ddc_pack_rx_frames: command 4 reply, 8 bytes per frame {SPEC_Q hi,lo, SPEC_I
+ * hi,lo, VOICE_Q hi,lo, VOICE_I hi,lo} (:228-271).  ddc_unpack_tx_frames:
+ * command 3 payload, 4 bytes {Q hi,lo, I hi,lo} (:206-227).  ddc_parse_params:
+ * command 1 payload {flags(bit3 TX, bit2 preamp), freq[21:16], [15:8], [7:0]}
+ * (:142-171).  Host memory, no ctx needed. */
+void ddc_pack_rx_frames(const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames, uint8_t *out);
+void ddc_unpack_tx_frames(const uint8_t *in, size_t n_frames, int16_t *tx_iq);
+void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_inc22);
+/* Applies a command-1 payload to a channel: tuning word and RX/TX direction. */
+int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4]);
+
+/* Packed-ADC helpers and the synthetic test signal of the benchmark
+ * (two tones + uniform noise, xorshift64* seeded 0x5EED0000 + channel). */
+void ddc_pack_adc12(const int16_t *samples, size_t n, uint8_t *packed);
+void ddc_unpack_adc12(const uint8_t *packed, size_t n, int16_t *samples);
+void ddc_synth_adc(uint32_t channel, uint32_t fs_adc, size_t n, int16_t *samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""The block/moment form of the CIC that the GPU kernels use (tools/cic_math.py)
+reproduces the clock-level oracle exactly, and the generated constants are what
+the formulas say."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import cic_math as cm  # noqa: E402
+
+from tests.test_oracle import nco12, wrap  # noqa: E402
+
+
+def test_piece_polynomials_are_the_taps():
+    h = cm.h_taps()
+    assert len(h) == 2556 and sum(h) == 1 << 45
+    for j in range(5):
+        for u in (0, 1, 17, 255, 511):
+            k = 512 * j + u
+            assert cm.p_piece(j, u) == (h[k] if k < len(h) else 0)
+
+
+def test_coef_and_gamma_tables():
+    C = cm.coef_table()
+    assert [C[j][4] for j in range(5)] == [1, -4, 6, -4, 1]
+    for j in range(5):
+        for d in (0, 3, 100, 511):
+            assert sum(C[j][e] * cm.binom_poly(d + e, e) for e in range(5)) == cm.p_piece(j, d)
+    G = cm.gamma_table()
+    for k in range(5):
+        for a in range(17):
+            assert sum(G[k][q] * cm.binom_poly(a + q, q) for q in range(5)) == \
+                cm.binom_poly(32 * a + 10 + k, k)
+
+
+def test_local_weights_fit_the_packed_dot_product():
+    # 16-bit weights, and 32-bit sums for 15-bit data
+    for i in range(5):
+        w = [cm.psi(i, s) for s in range(32)]
+        assert max(abs(v) for v in w) < 32768
+        assert sum(abs(v) for v in w) * (1 << 14) < (1 << 31)
+
+
+def test_sf_constants(orc):
+    sf = orc.nco_tables()[2]
+    K, r = cm.sf_constants([int(v) for v in sf])
+    fi = np.arange(2048, dtype=np.int64)
+    assert np.array_equal((fi * K + r) >> 24, sf.astype(np.int64))
+    assert 2047 * K + r < (1 << 32) and K < (1 << 24)
+
+
+def test_moment_form_equals_clock_level_oracle(orc):
+    rng = np.random.default_rng(5)
+    nblk = 9
+    n = 512 * nblk
+    phi = 777777
+    adc = rng.integers(-2048, 2048, n).astype(np.int16)
+    adc[100:140] = -2048
+    oi, oq = orc.RxFront(phi).run(np.concatenate([adc, np.zeros(512, np.int16)]))
+    s12, c12 = nco12(orc, phi, n)
+    for nco, want in ((s12, oi), (c12, oq)):
+        x = [int(v) for v in (wrap(adc.astype(np.int64) * nco, 23) >> 8)]
+        B = []
+        for b in range(nblk):
+            prev5 = x[512 * b - 5: 512 * b] if b else [0] * 5
+            B.append(cm.block_moments(prev5, x[512 * b: 512 * b + 512]))
+        y = cm.cic_from_moments(B)
+        assert y == [int(v) for v in want[:nblk + 1]]
+
+
+def test_generated_header_is_current(tmp_path):
+    p = tmp_path / "h.h"
+    cm.emit_header(str(p))
+    cur = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       "ua3reo-ddc-transceiver_amd", "csrc", "ddc_cic_consts.h")
+    assert open(cur).read() == p.read_text()

@@ -1,0 +1,500 @@
+/*
+ * Host side of the C ABI declared in include/ua3reo_ddc.h: context life cycle,
+ * tuning, kernel launches, bus-frame helpers.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ua3reo_ddc.h"
+#include "ddc_rx_kernels.hip.h"
+#include "ddc_tx_kernels.hip.h"
+
+struct ddc_ctx {
+    ddc_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    // device state, per channel
+    uint32_t *d_acc = nullptr;   // NCO phase << 10
+    uint32_t *d_phi = nullptr;   // tuning word << 10
+    uint32_t *d_carry[2] = {nullptr, nullptr};
+    int carry_sel = 0;
+    uint2 *d_nco_tab = nullptr;
+    // work buffers, sized for cap_blk blocks of 512 samples per channel
+    uint32_t cap_blk = 0;
+    uint32_t last_blk = 0;
+    unsigned long long *d_mom = nullptr;
+    int16_t *d_cic = nullptr;
+    int16_t *d_comp = nullptr;
+    // history saved between calls (layout independent of the call size)
+    unsigned long long *d_hist_mom = nullptr; // [ch][5][10]
+    int16_t *d_hist_cic = nullptr;            // [ch][64][2]
+    int16_t *d_hist_comp = nullptr;           // [ch][256][2]
+    // staging for the host-pointer entry points
+    uint8_t *d_in = nullptr;
+    size_t in_cap = 0;
+    int16_t *d_out = nullptr;
+    size_t out_cap = 0;
+    std::vector<uint32_t> h_phi;
+    ddc_tx_state tx;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(ddc_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, -EIO, std::string(#call) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+long rnd_half_away(double x) { return (long)(x >= 0 ? std::floor(x + 0.5) : -std::floor(-x + 0.5)); }
+
+// Coarse NCO table for the kernels and a check that the arithmetic fine-sine
+// shortcut reproduces the 2048-entry fine ROM.
+int build_nco_table(std::vector<uint2> &tab)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    tab.resize(2048);
+    for (int i = 0; i < 2048; i++) {
+        const int sc = (int)rnd_half_away(8191.0 * std::sin(two_pi * i / 2048.0));
+        const int cc = (int)rnd_half_away(8191.0 * std::cos(two_pi * i / 2048.0));
+        tab[i].x = ddc::pack_w(2 * sc, 2 * cc);
+        tab[i].y = ddc::pack_w(2 * cc, -2 * sc);
+    }
+    for (uint32_t fi = 0; fi < 2048; fi++) {
+        const long sf = rnd_half_away(8191.0 * std::sin(two_pi * fi / 4194304.0));
+        const long cf = rnd_half_away(8191.0 * std::cos(two_pi * fi / 4194304.0));
+        if ((long)((fi * DDC_SF_K + DDC_SF_R) >> 24) != sf || cf != 8191) return -1;
+    }
+    return 0;
+}
+
+int check_channel(ddc_ctx *ctx, int32_t ch)
+{
+    if (!ctx) return -EINVAL;
+    if (ch < -1 || ch >= (int32_t)ctx->cfg.n_channels)
+        return fail(ctx, -EINVAL, "channel out of range");
+    return 0;
+}
+
+int ensure_capacity(ddc_ctx *ctx, uint32_t n_blk)
+{
+    if (n_blk <= ctx->cap_blk) return 0;
+    const size_t nch = ctx->cfg.n_channels;
+    if (ctx->d_mom) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_mom) (void)hipFree(ctx->d_mom);
+    if (ctx->d_cic) (void)hipFree(ctx->d_cic);
+    if (ctx->d_comp) (void)hipFree(ctx->d_comp);
+    ctx->d_mom = nullptr; ctx->d_cic = nullptr; ctx->d_comp = nullptr; ctx->cap_blk = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mom, nch * (ddc::kMomHist + (size_t)n_blk) * 10 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_cic, nch * (ddc::kCicHist + (size_t)n_blk) * 2 * sizeof(int16_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_comp, nch * (ddc::kCompHist + (size_t)n_blk / 2) * 2 * sizeof(int16_t)));
+    ctx->cap_blk = n_blk;
+    return 0;
+}
+
+} // namespace
+
+namespace ddc {
+// history <-> work buffer moves: the work buffers are laid out for the block
+// count of the current call, the saved history is not.
+__global__ void ddc_rx_load_history(const unsigned long long *hm, const int16_t *hc, const int16_t *he,
+                                    unsigned long long *mom, int16_t *cic, int16_t *comp, uint32_t n_blk)
+{
+    const uint32_t ch = blockIdx.x, t = threadIdx.x, nf = n_blk / 2;
+    if (t < kMomHist * 10) mom[(size_t)ch * (kMomHist + n_blk) * 10 + t] = hm[(size_t)ch * kMomHist * 10 + t];
+    if (t < kCicHist)
+        reinterpret_cast<uint32_t *>(cic)[(size_t)ch * (kCicHist + n_blk) + t] =
+            reinterpret_cast<const uint32_t *>(hc)[(size_t)ch * kCicHist + t];
+    if (t < kCompHist)
+        reinterpret_cast<uint32_t *>(comp)[(size_t)ch * (kCompHist + nf) + t] =
+            reinterpret_cast<const uint32_t *>(he)[(size_t)ch * kCompHist + t];
+}
+
+__global__ void ddc_rx_save_history(unsigned long long *hm, int16_t *hc, int16_t *he,
+                                    const unsigned long long *mom, const int16_t *cic, const int16_t *comp,
+                                    uint32_t *acc0, const uint32_t *phi32v, uint32_t n_blk, uint32_t samples_lo)
+{
+    const uint32_t ch = blockIdx.x, t = threadIdx.x, nf = n_blk / 2;
+    if (t < kMomHist * 10)
+        hm[(size_t)ch * kMomHist * 10 + t] = mom[((size_t)ch * (kMomHist + n_blk) + n_blk) * 10 + t];
+    if (t < kCicHist)
+        reinterpret_cast<uint32_t *>(hc)[(size_t)ch * kCicHist + t] =
+            reinterpret_cast<const uint32_t *>(cic)[(size_t)ch * (kCicHist + n_blk) + n_blk + t];
+    if (t < kCompHist)
+        reinterpret_cast<uint32_t *>(he)[(size_t)ch * kCompHist + t] =
+            reinterpret_cast<const uint32_t *>(comp)[(size_t)ch * (kCompHist + nf) + nf + t];
+    if (t == 0) acc0[ch] += samples_lo * phi32v[ch];
+}
+} // namespace ddc
+
+extern "C" {
+
+const char *ddc_version(void) { return "ua3reo-ddc-amd 0.1 (gfx950)"; }
+
+const char *ddc_last_error(const ddc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int ddc_create(const ddc_config *cfg, ddc_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, -EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->n_channels == 0 || cfg->n_channels > (1u << 20))
+        return fail(nullptr, -EINVAL, "n_channels must be 1..2^20");
+    ddc_ctx *ctx = new ddc_ctx;
+    ctx->cfg = *cfg;
+    if (ctx->cfg.fs_adc == 0) ctx->cfg.fs_adc = DDC_ADC_CLOCK_DEFAULT;
+    auto bail = [&](int code) { std::string m = ctx->err; ddc_destroy(ctx); g_err = m; return code; };
+#define CREATE_TRY(call)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return bail(-EIO);                                                               \
+        }                                                                                    \
+    } while (0)
+    CREATE_TRY(hipSetDevice(cfg->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t nch = cfg->n_channels;
+    CREATE_TRY(hipMalloc(&ctx->d_acc, nch * 4));
+    CREATE_TRY(hipMalloc(&ctx->d_phi, nch * 4));
+    CREATE_TRY(hipMalloc(&ctx->d_carry[0], nch * 24));
+    CREATE_TRY(hipMalloc(&ctx->d_carry[1], nch * 24));
+    CREATE_TRY(hipMalloc(&ctx->d_nco_tab, 2048 * sizeof(uint2)));
+    CREATE_TRY(hipMalloc(&ctx->d_hist_mom, nch * ddc::kMomHist * 10 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&ctx->d_hist_cic, nch * ddc::kCicHist * 4));
+    CREATE_TRY(hipMalloc(&ctx->d_hist_comp, nch * ddc::kCompHist * 4));
+    CREATE_TRY(hipMemsetAsync(ctx->d_acc, 0, nch * 4, ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_phi, 0, nch * 4, ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_carry[0], 0, nch * 24, ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_carry[1], 0, nch * 24, ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_hist_mom, 0, nch * ddc::kMomHist * 10 * sizeof(unsigned long long), ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_hist_cic, 0, nch * ddc::kCicHist * 4, ctx->stream));
+    CREATE_TRY(hipMemsetAsync(ctx->d_hist_comp, 0, nch * ddc::kCompHist * 4, ctx->stream));
+    std::vector<uint2> tab;
+    if (build_nco_table(tab) != 0) {
+        ctx->err = "fine-sine shortcut does not reproduce the NCO fine ROM";
+        return bail(-EFAULT);
+    }
+    CREATE_TRY(hipMemcpyAsync(ctx->d_nco_tab, tab.data(), 2048 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
+                                      hipMemcpyHostToDevice, ctx->stream));
+    CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
+                                      hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_phi.assign(nch, 0);
+    {
+        int rc = ddc_tx_state_create(&ctx->tx, ctx->cfg.n_channels, ctx->stream);
+        if (rc != 0) { ctx->err = "TX state allocation failed"; return bail(rc); }
+    }
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+#undef CREATE_TRY
+    *out = ctx;
+    return 0;
+}
+
+void ddc_destroy(ddc_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
+                     ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
+                     ctx->d_out };
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    ddc_tx_state_destroy(&ctx->tx);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+uint32_t ddc_phrase_from_frequency(uint32_t freq_hz, uint32_t fs_adc, int *iq_swap)
+{
+    if (fs_adc == 0) fs_adc = DDC_ADC_CLOCK_DEFAULT;
+    bool inverted = false;
+    uint32_t f = freq_hz;
+    const uint32_t nyq = fs_adc / 2;
+    if (f > nyq) {
+        while (f > nyq) { f -= nyq; inverted = !inverted; }
+        if (inverted) f = nyq - f;
+    }
+    if (iq_swap) *iq_swap = inverted ? 1 : 0;
+    return (uint32_t)std::round(((double)f / (double)fs_adc) * 4194304.0);
+}
+
+uint32_t ddc_frequency_from_phrase(uint32_t phrase, uint32_t fs_adc)
+{
+    if (fs_adc == 0) fs_adc = DDC_ADC_CLOCK_DEFAULT;
+    return (uint32_t)(std::ceil(((double)phrase / 4194304.0) * (double)fs_adc / 100.0) * 100.0);
+}
+
+int ddc_tune(ddc_ctx *ctx, int32_t channel, uint32_t phi_inc22)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (phi_inc22 >> 22) return fail(ctx, -EINVAL, "tuning word wider than 22 bits");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const uint32_t lo = channel < 0 ? 0 : (uint32_t)channel;
+    const uint32_t hi = channel < 0 ? ctx->cfg.n_channels : (uint32_t)channel + 1;
+    for (uint32_t c = lo; c < hi; c++) ctx->h_phi[c] = phi_inc22 << 10;
+    // the staging vector must outlive the async copy: wait for it
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_phi + lo, ctx->h_phi.data() + lo, (hi - lo) * 4, hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_tune_many(ddc_ctx *ctx, const uint32_t *phi_inc22, uint32_t n)
+{
+    if (!ctx || !phi_inc22) return -EINVAL;
+    if (n != ctx->cfg.n_channels) return fail(ctx, -EINVAL, "ddc_tune_many: need one word per channel");
+    for (uint32_t c = 0; c < n; c++) {
+        if (phi_inc22[c] >> 22) return fail(ctx, -EINVAL, "tuning word wider than 22 bits");
+        ctx->h_phi[c] = phi_inc22[c] << 10;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_phi, ctx->h_phi.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_tune_hz(ddc_ctx *ctx, int32_t channel, uint32_t freq_hz, int *iq_swap)
+{
+    if (!ctx) return -EINVAL;
+    return ddc_tune(ctx, channel, ddc_phrase_from_frequency(freq_hz, ctx->cfg.fs_adc, iq_swap) & 0x3FFFFF);
+}
+
+int ddc_rx_reset(ddc_ctx *ctx, int32_t channel)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t lo = channel < 0 ? 0 : (size_t)channel;
+    const size_t n = channel < 0 ? ctx->cfg.n_channels : 1;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc + lo, 0, n * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_carry[0] + lo * 6, 0, n * 24, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_carry[1] + lo * 6, 0, n * 24, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_mom + lo * ddc::kMomHist * 10, 0,
+                                n * ddc::kMomHist * 10 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_cic + lo * ddc::kCicHist * 2, 0, n * ddc::kCicHist * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_comp + lo * ddc::kCompHist * 2, 0, n * ddc::kCompHist * 4, ctx->stream));
+    return 0;
+}
+
+int ddc_rx_set_phase(ddc_ctx *ctx, int32_t channel, uint32_t phase22)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0) return fail(ctx, -EINVAL, "ddc_rx_set_phase needs one channel");
+    const uint32_t v = (phase22 & 0x3FFFFF) << 10;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_acc + channel, &v, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_rx_get_phase(ddc_ctx *ctx, int32_t channel, uint32_t *phase22)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0 || !phase22) return fail(ctx, -EINVAL, "ddc_rx_get_phase needs one channel");
+    uint32_t v = 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_acc + channel, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *phase22 = v >> 10;
+    return 0;
+}
+
+int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                       int16_t *spec_iq, int16_t *voice_iq)
+{
+    if (!ctx) return -EINVAL;
+    if (samples == 0) return 0;
+    if (!adc12 || !spec_iq || !voice_iq) return fail(ctx, -EINVAL, "null buffer");
+    if (samples % DDC_DECIMATION) return fail(ctx, -EINVAL, "samples must be a multiple of 1024");
+    if (row_bytes % 16 || ((uintptr_t)adc12 % 16)) return fail(ctx, -EINVAL, "ADC rows must be 16-byte aligned");
+    if (row_bytes < samples / 2 * 3) return fail(ctx, -EINVAL, "row_bytes smaller than one row of samples");
+    const uint64_t n_blk64 = samples / 512;
+    const uint64_t total64 = n_blk64 * ctx->cfg.n_channels;
+    if (total64 >= (1ull << 31)) return fail(ctx, -EINVAL, "more than 2^31 blocks of 512 samples in one call");
+    const uint32_t n_blk = (uint32_t)n_blk64, total = (uint32_t)total64, nch = ctx->cfg.n_channels;
+    const uint32_t nf = n_blk / 2;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_capacity(ctx, n_blk);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp,
+                                                 ctx->d_mom, ctx->d_cic, ctx->d_comp, n_blk);
+    const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
+    uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
+    ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
+        adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
+    ctx->carry_sel ^= 1;
+    ddc::ddc_rx_cic_combine<<<(total + 255) / 256, 256, 0, st>>>(ctx->d_mom, n_blk, nch, ctx->d_cic);
+    const uint32_t nfr = nch * nf;
+    ddc::ddc_rx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(ctx->d_cic, n_blk, nch, ctx->d_comp, spec_iq);
+    ddc::ddc_rx_hilbert<<<(nfr + 255) / 256, 256, 0, st>>>(ctx->d_comp, nf, nch, voice_iq);
+    ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_mom,
+                                                 ctx->d_cic, ctx->d_comp, ctx->d_acc, ctx->d_phi, n_blk,
+                                                 (uint32_t)samples);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_blk = n_blk;
+    return 0;
+}
+
+int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                   int16_t *spec_iq, int16_t *voice_iq)
+{
+    if (!ctx) return -EINVAL;
+    if (samples == 0) return 0;
+    if (!adc12 || !spec_iq || !voice_iq) return fail(ctx, -EINVAL, "null buffer");
+    if (samples % DDC_DECIMATION) return fail(ctx, -EINVAL, "samples must be a multiple of 1024");
+    const size_t nch = ctx->cfg.n_channels;
+    const size_t need_row = samples / 2 * 3;
+    if (row_bytes < need_row) return fail(ctx, -EINVAL, "row_bytes smaller than one row of samples");
+    const size_t drow = (need_row + 255) / 256 * 256;
+    const size_t in_bytes = drow * nch;
+    const size_t out_elems = nch * (samples / DDC_DECIMATION) * 2;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    if (in_bytes > ctx->in_cap) {
+        if (ctx->d_in) (void)hipFree(ctx->d_in);
+        ctx->d_in = nullptr; ctx->in_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_in, in_bytes));
+        ctx->in_cap = in_bytes;
+    }
+    if (out_elems * 2 > ctx->out_cap) {
+        if (ctx->d_out) (void)hipFree(ctx->d_out);
+        ctx->d_out = nullptr; ctx->out_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_out, out_elems * 2 * sizeof(int16_t)));
+        ctx->out_cap = out_elems * 2;
+    }
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_in, drow, adc12, row_bytes, need_row, nch, hipMemcpyHostToDevice, ctx->stream));
+    int rc = ddc_rx_process_dev(ctx, ctx->d_in, drow, samples, ctx->d_out, ctx->d_out + out_elems);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(spec_iq, ctx->d_out, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(voice_iq, ctx->d_out + out_elems, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples)
+{
+    if (!ctx || !cic_iq) return -EINVAL;
+    const uint32_t n_blk = (uint32_t)(samples / 512);
+    if (n_blk == 0 || n_blk != ctx->last_blk) return fail(ctx, -EINVAL, "ddc_rx_read_cic: size differs from the last call");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpy2DAsync(cic_iq, (size_t)n_blk * 4, ctx->d_cic + (size_t)ddc::kCicHist * 2,
+                                  (size_t)(ddc::kCicHist + n_blk) * 4, (size_t)n_blk * 4, ctx->cfg.n_channels,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_sync(ddc_ctx *ctx)
+{
+    if (!ctx) return -EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void *ddc_stream(ddc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+/* ---- bus frames -------------------------------------------------------- */
+
+void ddc_pack_rx_frames(const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames, uint8_t *out)
+{
+    for (size_t n = 0; n < n_frames; n++) {
+        const uint16_t si = (uint16_t)spec_iq[2 * n], sq = (uint16_t)spec_iq[2 * n + 1];
+        const uint16_t vi = (uint16_t)voice_iq[2 * n], vq = (uint16_t)voice_iq[2 * n + 1];
+        uint8_t *o = out + 8 * n;
+        o[0] = (uint8_t)(sq >> 8); o[1] = (uint8_t)sq; o[2] = (uint8_t)(si >> 8); o[3] = (uint8_t)si;
+        o[4] = (uint8_t)(vq >> 8); o[5] = (uint8_t)vq; o[6] = (uint8_t)(vi >> 8); o[7] = (uint8_t)vi;
+    }
+}
+
+void ddc_unpack_tx_frames(const uint8_t *in, size_t n_frames, int16_t *tx_iq)
+{
+    for (size_t n = 0; n < n_frames; n++) {
+        const uint8_t *p = in + 4 * n;
+        tx_iq[2 * n + 1] = (int16_t)(((uint16_t)p[0] << 8) | p[1]); /* Q first on the bus */
+        tx_iq[2 * n] = (int16_t)(((uint16_t)p[2] << 8) | p[3]);
+    }
+}
+
+void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_inc22)
+{
+    if (preamp) *preamp = (in[0] >> 2) & 1;
+    if (tx) *tx = (in[0] >> 3) & 1;
+    if (phi_inc22) *phi_inc22 = ((uint32_t)(in[1] & 0x3F) << 16) | ((uint32_t)in[2] << 8) | in[3];
+}
+
+int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
+{
+    int tx = 0, pre = 0;
+    uint32_t phi = 0;
+    ddc_parse_params(in, &tx, &pre, &phi);
+    (void)pre;
+    (void)tx;
+    return ddc_tune(ctx, channel, phi);
+}
+
+/* ---- packed ADC words and the synthetic bench signal ------------------- */
+
+void ddc_pack_adc12(const int16_t *samples, size_t n, uint8_t *packed)
+{
+    for (size_t i = 0; i < n; i += 2) {
+        const unsigned s0 = (unsigned)samples[i] & 0xFFF;
+        const unsigned s1 = (i + 1 < n ? (unsigned)samples[i + 1] : 0u) & 0xFFF;
+        uint8_t *b = packed + (i / 2) * 3;
+        b[0] = (uint8_t)(s0 & 0xFF);
+        b[1] = (uint8_t)((s0 >> 8) | ((s1 & 0xF) << 4));
+        b[2] = (uint8_t)(s1 >> 4);
+    }
+}
+
+void ddc_unpack_adc12(const uint8_t *packed, size_t n, int16_t *samples)
+{
+    for (size_t i = 0; i < n; i += 2) {
+        const uint8_t *b = packed + (i / 2) * 3;
+        const int s0 = b[0] | ((b[1] & 0x0F) << 8);
+        const int s1 = (b[1] >> 4) | (b[2] << 4);
+        samples[i] = (int16_t)((s0 ^ 0x800) - 0x800);
+        if (i + 1 < n) samples[i + 1] = (int16_t)((s1 ^ 0x800) - 0x800);
+    }
+}
+
+void ddc_synth_adc(uint32_t channel, uint32_t fs_adc, size_t n, int16_t *samples)
+{
+    if (fs_adc == 0) fs_adc = DDC_ADC_CLOCK_DEFAULT;
+    uint64_t s = 0x5EED0000ull + channel;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double f1 = 1.0e6 + 48.0e3 * channel, f2 = f1 + 1.0e3;
+    const double w1 = two_pi * f1 / fs_adc, w2 = two_pi * f2 / fs_adc;
+    for (size_t i = 0; i < n; i++) {
+        s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+        const uint64_t r = s * 0x2545F4914F6CDD1Dull;
+        const int noise = (int)(r >> 57) - 64; /* uniform in [-64, 63] */
+        long v = std::lround(1400.0 * std::sin(w1 * (double)i) + 300.0 * std::sin(w2 * (double)i)) + noise;
+        if (v > 2047) v = 2047;
+        if (v < -2047) v = -2047;
+        samples[i] = (int16_t)v;
+    }
+}
+
+} /* extern "C" */

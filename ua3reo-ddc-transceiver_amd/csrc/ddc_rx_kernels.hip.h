@@ -1,0 +1,440 @@
+/*
+ * RX kernels of the MI355X DDC: packed 12-bit ADC words -> SPEC / VOICE I/Q.
+ *
+ * Replaces, bit for bit, the FPGA RX datapath of the reference:
+ *   NCO            FPGA/nco.qsys:56-85, nco/synthesis/submodules/nco_nco_ii_0.v:299-420
+ *   nco_shift      FPGA/nco_shift.v:9
+ *   mixer (x2)     FPGA/mixer.v:55-71, FPGA/rx_mixer_shift.v:9
+ *   rx_cic (x2)    FPGA/rx_cic.vhd:147-404
+ *   rx_ciccomp(x2) FPGA/rx_ciccomp.vhd:81-146,339-361,425-616
+ *   rx_hilb (I)    FPGA/rx_hilb.vhd:77-332,902-935
+ *   data_delay (Q) FPGA/data_delay.v:16-28 with delay_length=130 (FPGA/UA3REO.bdf:1692-1696)
+ *
+ * The hardware is serial in time.  Here time is cut into windows of 512 samples
+ * and every window is reduced independently to five exact 64-bit moments from
+ * which the CIC outputs follow by a fixed 5x5 integer combination (algebra in
+ * tools/cic_math.py), so one tuned channel parallelises over time and many
+ * channels parallelise over both.
+ *
+ * Kernel 1 (ddc_rx_front) is the only one that touches the ADC stream; it is
+ * bound by vector-ALU issue (about 21 integer lane-ops per sample), reads every
+ * ADC byte once (1.5 B per sample) and writes 80 B of moments per 512 samples.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ddc_cic_consts.h"
+#include "ddc_coeffs.h"
+
+namespace ddc {
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+constexpr int kChunk = 32;        // samples per chunk
+constexpr int kChunksPerBlk = 16; // 512 / 32
+constexpr int kBlk = 512;         // CIC decimation
+constexpr int kBlkBytes = 768;    // 512 samples * 1.5 B
+constexpr int kChunkBytes = 48;
+constexpr int kFrontThreads = 256;
+constexpr int kMomHist = 5;   // windows of history a CIC output reaches back
+constexpr int kCicHist = 64;  // rx_ciccomp reaches back 64 inputs
+constexpr int kCompHist = 256; // rx_hilb reaches back 255, data_delay 130
+
+constexpr int PSI[5][32] = DDC_PSI_TABLE;
+constexpr long long GAM[5][5] = DDC_GAMMA_TABLE;
+constexpr long long COEF[5][5] = DDC_COEF_TABLE;
+
+__host__ __device__ constexpr long long binom_gen(int n, int k)
+{
+    long long num = 1;
+    for (int i = 0; i < k; i++) num *= (n - i);
+    long long den = 1;
+    for (int i = 1; i <= k; i++) den *= i;
+    return num / den;
+}
+// chunk-local weight of sample s for moment i: C(15 - s + i, i)
+__host__ __device__ constexpr int psi_w(int i, int s) { return (int)binom_gen(15 - s + i, i); }
+__host__ __device__ constexpr unsigned pack_w(int lo, int hi)
+{
+    return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+}
+constexpr bool psi_matches_header()
+{
+    for (int i = 0; i < 5; i++)
+        for (int s = 0; s < 32; s++)
+            if (psi_w(i, s) != PSI[i][s]) return false;
+    return true;
+}
+static_assert(psi_matches_header(), "local moment weights differ from tools/cic_math.py");
+
+__device__ __forceinline__ int dot2(unsigned a, unsigned w, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, w), c, false);
+}
+
+// One NCO + mixer step.  tab: 2048 coarse entries {2*sc | 2*cc<<16, 2*cc | (-2*sc)<<16}.
+// acc32 holds the 22-bit phase accumulator in its top 22 bits, so the natural
+// 32-bit wrap is the accumulator's wrap.  Returns the two 15-bit CIC inputs
+// wrap23(adc * nco12) >> 8.
+__device__ __forceinline__ void nco_mix(const uint2 *tab, uint32_t acc32, int adc, int &xi, int &xq)
+{
+    const uint32_t off = (acc32 >> 18) & 0x3FF8u;
+    const uint2 e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off);
+    const uint32_t fi = __builtin_amdgcn_ubfe(acc32, 10, 11);
+    const uint32_t t = __umul24(fi, DDC_SF_K) + DDC_SF_R;          // t >> 24 = fine sine (0..25)
+    const uint32_t w = __builtin_amdgcn_perm(t, 0x1FFFu, 0x0C070100u); // {8191, t>>24}
+    // 2*(sc*8191 + cc*sf + 4096): the 14-bit output's top 12 bits are bits 31..16
+    const int s = dot2(e.x, w, 8192);
+    const int c = dot2(e.y, w, 8192);
+    const int pi = __mul24(adc, s >> 16);
+    const int pq = __mul24(adc, c >> 16);
+    xi = __builtin_amdgcn_sbfe(pi, 8, 15);
+    xq = __builtin_amdgcn_sbfe(pq, 8, 15);
+}
+
+__device__ __forceinline__ unsigned pack16(int lo, int hi)
+{
+    return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u);
+}
+
+// eight 12-bit samples from three dwords
+__device__ __forceinline__ void unpack8(uint32_t d0, uint32_t d1, uint32_t d2, int (&a)[8])
+{
+    a[0] = __builtin_amdgcn_sbfe((int)d0, 0, 12);
+    a[1] = __builtin_amdgcn_sbfe((int)d0, 12, 12);
+    a[2] = __builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(d1, d0, 24), 0, 12);
+    a[3] = __builtin_amdgcn_sbfe((int)d1, 4, 12);
+    a[4] = __builtin_amdgcn_sbfe((int)d1, 16, 12);
+    a[5] = __builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(d2, d1, 28), 0, 12);
+    a[6] = __builtin_amdgcn_sbfe((int)d2, 8, 12);
+    a[7] = (int)d2 >> 20;
+}
+
+// Running sums over the chunk steps of one window.  T[i][q] ends as
+// sum_a C(a'+q, q) mu_i(a); the widths are the smallest that provably hold the
+// value for 15-bit inputs (bounds in tools/cic_math.py / DESIGN.md).
+struct Cascade {
+    int t00, t01, t02, t03, t10, t11, t20, t30;
+    long long t04, t12, t13, t21, t22, t31, t40;
+    __device__ __forceinline__ void clear()
+    {
+        t00 = t01 = t02 = t03 = t10 = t11 = t20 = t30 = 0;
+        t04 = t12 = t13 = t21 = t22 = t31 = t40 = 0;
+    }
+    __device__ __forceinline__ void step(const int (&mu)[5])
+    {
+        t00 += mu[0]; t01 += t00; t02 += t01; t03 += t02; t04 += t03;
+        t10 += mu[1]; t11 += t10; t12 += t11; t13 += t12;
+        t20 += mu[2]; t21 += t20; t22 += t21;
+        t30 += mu[3]; t31 += t30;
+        t40 += mu[4];
+    }
+    // B[e] = sum_{i<=e} sum_{q<=e-i} GAM[e-i][q] * T[i][q]   (mod 2^64)
+    __device__ __forceinline__ void moments(unsigned long long (&B)[5]) const
+    {
+        const long long T[5][5] = {
+            { t00, t01, t02, t03, t04 }, { t10, t11, t12, t13, 0 }, { t20, t21, t22, 0, 0 },
+            { t30, t31, 0, 0, 0 },       { t40, 0, 0, 0, 0 } };
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            unsigned long long acc = 0;
+#pragma unroll
+            for (int i = 0; i <= e; i++)
+#pragma unroll
+                for (int q = 0; q <= e - i; q++)
+                    acc += (unsigned long long)GAM[e - i][q] * (unsigned long long)T[i][q];
+            B[e] = acc;
+        }
+    }
+};
+
+template <int P>
+__device__ __forceinline__ void pair_acc(unsigned pk_i, unsigned pk_q, int (&mi)[5], int (&mq)[5])
+{
+    constexpr unsigned w0 = pack_w(1, 1);
+    constexpr unsigned w1 = pack_w(psi_w(1, 2 * P), psi_w(1, 2 * P + 1));
+    constexpr unsigned w2 = pack_w(psi_w(2, 2 * P), psi_w(2, 2 * P + 1));
+    constexpr unsigned w3 = pack_w(psi_w(3, 2 * P), psi_w(3, 2 * P + 1));
+    constexpr unsigned w4 = pack_w(psi_w(4, 2 * P), psi_w(4, 2 * P + 1));
+    mi[0] = dot2(pk_i, w0, mi[0]); mq[0] = dot2(pk_q, w0, mq[0]);
+    mi[1] = dot2(pk_i, w1, mi[1]); mq[1] = dot2(pk_q, w1, mq[1]);
+    mi[2] = dot2(pk_i, w2, mi[2]); mq[2] = dot2(pk_q, w2, mq[2]);
+    mi[3] = dot2(pk_i, w3, mi[3]); mq[3] = dot2(pk_q, w3, mq[3]);
+    mi[4] = dot2(pk_i, w4, mi[4]); mq[4] = dot2(pk_q, w4, mq[4]);
+}
+
+// The five samples s = 27..31 of a chunk (pairs 13 (high half only), 14, 15),
+// added with sign SGN: the part of a natural chunk that belongs to the next
+// window.
+template <int SGN>
+__device__ __forceinline__ void tail5_acc(const unsigned (&pk)[3], int (&m)[5])
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const unsigned wa = pack_w(0, SGN * psi_w(i, 27));
+        const unsigned wb = pack_w(SGN * psi_w(i, 28), SGN * psi_w(i, 29));
+        const unsigned wc = pack_w(SGN * psi_w(i, 30), SGN * psi_w(i, 31));
+        m[i] = dot2(pk[0], wa, m[i]);
+        m[i] = dot2(pk[1], wb, m[i]);
+        m[i] = dot2(pk[2], wc, m[i]);
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d1, uint32_t d2,
+                                       uint32_t &acc32, uint32_t phi32, int (&mi)[5], int (&mq)[5],
+                                       unsigned (&last_i)[3], unsigned (&last_q)[3])
+{
+    int a[8];
+    unpack8(d0, d1, d2, a);
+    unsigned pi[4], pq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int xi0, xq0, xi1, xq1;
+        nco_mix(tab, acc32, a[2 * k], xi0, xq0);
+        acc32 += phi32;
+        nco_mix(tab, acc32, a[2 * k + 1], xi1, xq1);
+        acc32 += phi32;
+        pi[k] = pack16(xi0, xi1);
+        pq[k] = pack16(xq0, xq1);
+    }
+    pair_acc<4 * G + 0>(pi[0], pq[0], mi, mq);
+    pair_acc<4 * G + 1>(pi[1], pq[1], mi, mq);
+    pair_acc<4 * G + 2>(pi[2], pq[2], mi, mq);
+    pair_acc<4 * G + 3>(pi[3], pq[3], mi, mq);
+    if (G == 3) {
+        last_i[0] = pi[1]; last_i[1] = pi[2]; last_i[2] = pi[3];
+        last_q[0] = pq[1]; last_q[1] = pq[2]; last_q[2] = pq[3];
+    }
+}
+
+/*
+ * Kernel 1.  One thread owns one natural block of 512 samples of one channel
+ * (global block id g = channel * n_blk + block); a workgroup owns 256
+ * consecutive ids.  The ADC bytes of the workgroup are staged through LDS in
+ * 16 slices of 256 x 48 B so that HBM is read in whole coalesced 16-byte lanes
+ * while every thread walks its own 768-byte run.
+ *
+ *   mom  [channel][kMomHist + n_blk][2][5] u64 : window moments, I then Q;
+ *        this kernel writes records kMomHist + block
+ *   carry_in / carry_out [channel][6] : packed mixer outputs of the last six
+ *        samples of the previous / this call (I pairs 13..15, Q pairs 13..15)
+ */
+__global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
+    const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t total_blocks,
+    const uint32_t *__restrict__ acc0, const uint32_t *__restrict__ phi32v,
+    const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out,
+    unsigned long long *__restrict__ mom, const uint2 *__restrict__ nco_tab)
+{
+    __shared__ uint2 tab[2048];
+    __shared__ uint4 stage[2][3 * kFrontThreads];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t g0 = blockIdx.x * kFrontThreads;
+    for (uint32_t i = tid; i < 2048; i += kFrontThreads) tab[i] = nco_tab[i];
+
+    // staging sources: 16-byte piece q = tid + 256 j belongs to thread q / 3
+    const uint8_t *src[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t q = tid + kFrontThreads * j;
+        uint32_t go = g0 + q / 3;
+        go = go < total_blocks ? go : total_blocks - 1;
+        const uint32_t cho = go / n_blk, bo = go - cho * n_blk;
+        src[j] = adc + (size_t)cho * row_bytes + (size_t)bo * kBlkBytes + (q % 3) * 16;
+    }
+
+    const uint32_t g = g0 + tid;
+    const bool active = g < total_blocks;
+    const uint32_t gc = active ? g : total_blocks - 1;
+    const uint32_t ch = gc / n_blk, b = gc - ch * n_blk;
+    const uint32_t phi32 = phi32v[ch];
+    uint32_t acc32 = acc0[ch] + (b * (uint32_t)kBlk) * phi32;
+
+    uint4 pre[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) pre[j] = *reinterpret_cast<const uint4 *>(src[j]);
+
+    Cascade ci, cq;
+    ci.clear();
+    cq.clear();
+
+    __syncthreads(); // tab is ready
+
+    // step 0: the five samples before this block open the window
+    {
+        unsigned pki[3], pkq[3];
+        if (b == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pki[k] = carry_in[ch * 6 + k];
+                pkq[k] = carry_in[ch * 6 + 3 + k];
+            }
+        } else {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(
+                adc + (size_t)ch * row_bytes + (size_t)b * kBlkBytes - 12);
+            int a[8];
+            unpack8(p[0], p[1], p[2], a);
+            uint32_t ph = acc32 - 6u * phi32;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int xi0, xq0, xi1, xq1;
+                nco_mix(tab, ph, a[2 + 2 * k], xi0, xq0);
+                ph += phi32;
+                nco_mix(tab, ph, a[3 + 2 * k], xi1, xq1);
+                ph += phi32;
+                pki[k] = pack16(xi0, xi1);
+                pkq[k] = pack16(xq0, xq1);
+            }
+        }
+        int mi[5] = {0, 0, 0, 0, 0}, mq[5] = {0, 0, 0, 0, 0};
+        tail5_acc<1>(pki, mi);
+        tail5_acc<1>(pkq, mq);
+        ci.step(mi);
+        cq.step(mq);
+    }
+
+#pragma unroll
+    for (int j = 0; j < 3; j++) stage[0][tid + kFrontThreads * j] = pre[j];
+    __syncthreads();
+
+    unsigned last_i[3] = {0, 0, 0}, last_q[3] = {0, 0, 0};
+#pragma unroll 1
+    for (int a = 0; a < kChunksPerBlk; a++) {
+        if (a + 1 < kChunksPerBlk) {
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                pre[j] = *reinterpret_cast<const uint4 *>(src[j] + (a + 1) * kChunkBytes);
+        }
+        const uint4 *mine = &stage[a & 1][3 * tid];
+        const uint4 v0 = mine[0], v1 = mine[1], v2 = mine[2];
+        int mi[5] = {0, 0, 0, 0, 0}, mq[5] = {0, 0, 0, 0, 0};
+        group8<0>(tab, v0.x, v0.y, v0.z, acc32, phi32, mi, mq, last_i, last_q);
+        group8<1>(tab, v0.w, v1.x, v1.y, acc32, phi32, mi, mq, last_i, last_q);
+        group8<2>(tab, v1.z, v1.w, v2.x, acc32, phi32, mi, mq, last_i, last_q);
+        group8<3>(tab, v2.y, v2.z, v2.w, acc32, phi32, mi, mq, last_i, last_q);
+        if (a == kChunksPerBlk - 1) { // the newest five samples open the next window
+            tail5_acc<-1>(last_i, mi);
+            tail5_acc<-1>(last_q, mq);
+        }
+        ci.step(mi);
+        cq.step(mq);
+        if (a + 1 < kChunksPerBlk) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) stage[(a + 1) & 1][tid + kFrontThreads * j] = pre[j];
+            __syncthreads();
+        }
+    }
+
+    if (!active) return;
+    unsigned long long Bi[5], Bq[5];
+    ci.moments(Bi);
+    cq.moments(Bq);
+    unsigned long long *rec = mom + ((size_t)ch * (kMomHist + n_blk) + kMomHist + b) * 10;
+#pragma unroll
+    for (int e = 0; e < 5; e++) {
+        rec[e] = Bi[e];
+        rec[5 + e] = Bq[e];
+    }
+    if (b == n_blk - 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            carry_out[ch * 6 + k] = last_i[k];
+            carry_out[ch * 6 + 3 + k] = last_q[k];
+        }
+    }
+}
+
+/*
+ * Kernel 2.  rx_cic output m of this call from the moments of windows m-5..m-1
+ * (records m..m+4): y = wrap60(sum_j sum_e COEF[j][e] * B[m-1-j][e]) >> 44
+ * (FPGA/rx_cic.vhd:391).  cic: [channel][kCicHist + n_blk][2] int16.
+ */
+__global__ void ddc_rx_cic_combine(const unsigned long long *__restrict__ mom, uint32_t n_blk,
+                                   uint32_t n_ch, int16_t *__restrict__ cic)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_ch * n_blk) return;
+    const uint32_t ch = (uint32_t)(gid / n_blk), m = (uint32_t)(gid - (uint64_t)ch * n_blk);
+    const unsigned long long *base = mom + ((size_t)ch * (kMomHist + n_blk) + m) * 10;
+    unsigned long long acc[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const unsigned long long *rec = base + (size_t)(4 - j) * 10;
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            acc[0] += (unsigned long long)COEF[j][e] * rec[e];
+            acc[1] += (unsigned long long)COEF[j][e] * rec[5 + e];
+        }
+    }
+    int16_t *o = cic + ((size_t)ch * (kCicHist + n_blk) + kCicHist + m) * 2;
+    o[0] = (int16_t)((long long)(acc[0] << 4) >> 48);
+    o[1] = (int16_t)((long long)(acc[1] << 4) >> 48);
+}
+
+// convergent rounding as the generated HDL codes it, on the low `bits` bits
+__device__ __forceinline__ int cround32(uint32_t v, int s, int bits)
+{
+    const int sh = 32 - bits;
+    const int t = (int)(v << sh) >> sh;
+    const uint32_t u = (uint32_t)t + ((1u << (s - 1)) - 1u) + (((uint32_t)t >> s) & 1u);
+    return ((int)(u << sh) >> sh) >> s;
+}
+
+__constant__ int16_t c_rx_ciccomp_h[65];
+__constant__ int16_t c_rx_hilb_c[256];
+
+/*
+ * Kernel 3.  rx_ciccomp: e[n] = wrap16(cround(sum_{i=0..64} h[i] * c[2n-i], 15))
+ * for I and Q (FPGA/rx_ciccomp.vhd:616; only the low 31 bits of the sum matter).
+ * Writes SPEC I/Q to the caller and to comp: [channel][kCompHist + nf][2].
+ */
+__global__ void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, uint32_t n_ch,
+                               int16_t *__restrict__ comp, int16_t *__restrict__ spec_iq)
+{
+    const uint32_t nf = n_blk / 2;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_ch * nf) return;
+    const uint32_t ch = (uint32_t)(gid / nf), n = (uint32_t)(gid - (uint64_t)ch * nf);
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(cic) +
+                        ((size_t)ch * (kCicHist + n_blk) + kCicHist + 2 * (size_t)n);
+    uint32_t ai = 0, aq = 0;
+#pragma unroll 13
+    for (int i = 0; i < 65; i++) {
+        const uint32_t v = x[-i];
+        const int h = c_rx_ciccomp_h[i];
+        ai += (uint32_t)(h * (int)(int16_t)(v & 0xFFFFu));
+        aq += (uint32_t)(h * ((int)v >> 16));
+    }
+    const int16_t ei = (int16_t)cround32(ai, 15, 31), eq = (int16_t)cround32(aq, 15, 31);
+    const uint32_t packed = (uint32_t)(uint16_t)ei | ((uint32_t)(uint16_t)eq << 16);
+    reinterpret_cast<uint32_t *>(comp)[(size_t)ch * (kCompHist + nf) + kCompHist + n] = packed;
+    reinterpret_cast<uint32_t *>(spec_iq)[(size_t)ch * nf + n] = packed;
+}
+
+/*
+ * Kernel 4.  VOICE_I = rx_hilb(e_I): wrap16(cround(wrap30(sum_k cround(c[k]*x[n-k], 1)), 14))
+ * (FPGA/rx_hilb.vhd:902-935); VOICE_Q = e_Q delayed by 130 (FPGA/data_delay.v).
+ */
+__global__ void ddc_rx_hilbert(const int16_t *__restrict__ comp, uint32_t nf, uint32_t n_ch,
+                               int16_t *__restrict__ voice_iq)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_ch * nf) return;
+    const uint32_t ch = (uint32_t)(gid / nf), n = (uint32_t)(gid - (uint64_t)ch * nf);
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(comp) +
+                        ((size_t)ch * (kCompHist + nf) + kCompHist + n);
+    uint32_t acc = 0;
+#pragma unroll 16
+    for (int k = 0; k < 256; k++) {
+        const int m = (int)c_rx_hilb_c[k] * (int)(int16_t)(x[-k] & 0xFFFFu);
+        acc += (uint32_t)((m + ((m >> 1) & 1)) >> 1);
+    }
+    const int16_t vi = (int16_t)cround32(acc, 14, 30);
+    const int16_t vq = (int16_t)((int)x[-130] >> 16);
+    reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
+        (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
+}
+
+} // namespace ddc

@@ -1,0 +1,239 @@
+"""ctypes binding of libua3reo_ddc.so.
+
+The library is the product; this module only marshals pointers.  It fails
+loudly when the shared object is missing -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+DECIMATION = 1024
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_PKG, "libua3reo_ddc.so")
+_CSRC = os.path.join(_PKG, "csrc")
+
+
+class DdcError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _SO
+
+
+def build_native(force=False):
+    """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))]
+    hdr = os.path.join(os.path.dirname(_PKG), "include", "ua3reo_ddc.h")
+    newest = max(os.path.getmtime(p) for p in srcs + [hdr])
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= newest:
+        return _SO
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", _SO, os.path.join(_CSRC, "ddc_lib.hip")]
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise DdcError("native library %s is missing: run __graft_entry__.build() "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % _SO)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7.  When
+    # torch is installed, load it first so that this library binds to the same
+    # runtime instance instead of bringing in a second one from /opt/rocm (two
+    # runtimes in one process cannot both open the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(_SO)
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32
+    L.ddc_create.argtypes = [vp, C.POINTER(vp)]
+    L.ddc_destroy.argtypes = [vp]
+    L.ddc_destroy.restype = None
+    L.ddc_last_error.argtypes = [vp]
+    L.ddc_last_error.restype = C.c_char_p
+    L.ddc_version.restype = C.c_char_p
+    L.ddc_tune.argtypes = [vp, i32, u32]
+    L.ddc_tune_hz.argtypes = [vp, i32, u32, C.POINTER(C.c_int)]
+    L.ddc_tune_many.argtypes = [vp, vp, u32]
+    L.ddc_phrase_from_frequency.argtypes = [u32, u32, C.POINTER(C.c_int)]
+    L.ddc_phrase_from_frequency.restype = u32
+    L.ddc_frequency_from_phrase.argtypes = [u32, u32]
+    L.ddc_frequency_from_phrase.restype = u32
+    L.ddc_rx_reset.argtypes = [vp, i32]
+    L.ddc_rx_set_phase.argtypes = [vp, i32, u32]
+    L.ddc_rx_get_phase.argtypes = [vp, i32, C.POINTER(u32)]
+    L.ddc_rx_process_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.ddc_rx_process.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.ddc_rx_read_cic.argtypes = [vp, vp, sz]
+    L.ddc_sync.argtypes = [vp]
+    L.ddc_stream.argtypes = [vp]
+    L.ddc_stream.restype = vp
+    L.ddc_pack_rx_frames.argtypes = [vp, vp, sz, vp]
+    L.ddc_pack_rx_frames.restype = None
+    L.ddc_unpack_tx_frames.argtypes = [vp, sz, vp]
+    L.ddc_unpack_tx_frames.restype = None
+    L.ddc_parse_params.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(u32)]
+    L.ddc_parse_params.restype = None
+    L.ddc_set_params.argtypes = [vp, i32, vp]
+    L.ddc_pack_adc12.argtypes = [vp, sz, vp]
+    L.ddc_pack_adc12.restype = None
+    L.ddc_unpack_adc12.argtypes = [vp, sz, vp]
+    L.ddc_unpack_adc12.restype = None
+    L.ddc_synth_adc.argtypes = [u32, u32, sz, vp]
+    L.ddc_synth_adc.restype = None
+    _lib = L
+    return L
+
+
+class _Config(C.Structure):
+    _fields_ = [("n_channels", C.c_uint32), ("fs_adc", C.c_uint32), ("device", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Ddc:
+    """One ddc_ctx: N tuned channels on one GPU."""
+
+    def __init__(self, n_channels, fs_adc=0, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        cfg = _Config(n_channels, fs_adc, device, 0)
+        rc = self._L.ddc_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise DdcError("ddc_create failed (%d): %s" % (rc, self._L.ddc_last_error(None).decode()))
+        self.n_channels = n_channels
+
+    def close(self):
+        if self._h:
+            self._L.ddc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DdcError("error %d: %s" % (rc, self._L.ddc_last_error(self._h).decode()))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def tune(self, channel, phi):
+        self._check(self._L.ddc_tune(self._h, channel, int(phi)))
+
+    def tune_many(self, phis):
+        a = np.ascontiguousarray(phis, dtype=np.uint32)
+        self._check(self._L.ddc_tune_many(self._h, _np_ptr(a), a.size))
+
+    def tune_hz(self, channel, freq):
+        sw = C.c_int()
+        self._check(self._L.ddc_tune_hz(self._h, channel, int(freq), C.byref(sw)))
+        return bool(sw.value)
+
+    def rx_reset(self, channel=-1):
+        self._check(self._L.ddc_rx_reset(self._h, channel))
+
+    def rx_set_phase(self, channel, phase):
+        self._check(self._L.ddc_rx_set_phase(self._h, channel, int(phase)))
+
+    def rx_get_phase(self, channel):
+        v = C.c_uint32()
+        self._check(self._L.ddc_rx_get_phase(self._h, channel, C.byref(v)))
+        return v.value
+
+    def rx_process(self, packed_rows, samples):
+        """Host path. packed_rows: uint8 [n_channels][row_bytes]; returns spec, voice
+        int16 [n_channels][samples/1024][2]."""
+        a = np.ascontiguousarray(packed_rows, dtype=np.uint8)
+        assert a.ndim == 2 and a.shape[0] == self.n_channels
+        nf = samples // DECIMATION
+        spec = np.zeros((self.n_channels, nf, 2), np.int16)
+        voice = np.zeros((self.n_channels, nf, 2), np.int16)
+        self._check(self._L.ddc_rx_process(self._h, _np_ptr(a), a.shape[1], samples, _np_ptr(spec),
+                                           _np_ptr(voice)))
+        return spec, voice
+
+    def rx_process_dev(self, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr):
+        """Device path: raw device addresses (ints), asynchronous on the ctx stream."""
+        self._check(self._L.ddc_rx_process_dev(self._h, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr))
+
+    def rx_read_cic(self, samples):
+        out = np.zeros((self.n_channels, samples // 512, 2), np.int16)
+        self._check(self._L.ddc_rx_read_cic(self._h, _np_ptr(out), samples))
+        return out
+
+    def sync(self):
+        self._check(self._L.ddc_sync(self._h))
+
+    def stream(self):
+        return self._L.ddc_stream(self._h)
+
+
+def pack_adc12(samples):
+    s = np.ascontiguousarray(samples, dtype=np.int16)
+    out = np.zeros((s.size + 1) // 2 * 3, np.uint8)
+    lib().ddc_pack_adc12(_np_ptr(s), s.size, _np_ptr(out))
+    return out
+
+
+def unpack_adc12(packed, n):
+    p = np.ascontiguousarray(packed, dtype=np.uint8)
+    out = np.zeros(n, np.int16)
+    lib().ddc_unpack_adc12(_np_ptr(p), n, _np_ptr(out))
+    return out
+
+
+def synth_adc(channel, n, fs_adc=0):
+    out = np.zeros(n, np.int16)
+    lib().ddc_synth_adc(channel, fs_adc, n, _np_ptr(out))
+    return out
+
+
+def phrase_from_frequency(freq, fs_adc=0):
+    sw = C.c_int()
+    v = lib().ddc_phrase_from_frequency(int(freq), fs_adc, C.byref(sw))
+    return int(v), bool(sw.value)
+
+
+def frequency_from_phrase(phrase, fs_adc=0):
+    return int(lib().ddc_frequency_from_phrase(int(phrase), fs_adc))
+
+
+def pack_rx_frames(spec_iq, voice_iq):
+    s = np.ascontiguousarray(spec_iq, dtype=np.int16).reshape(-1, 2)
+    v = np.ascontiguousarray(voice_iq, dtype=np.int16).reshape(-1, 2)
+    out = np.zeros(8 * s.shape[0], np.uint8)
+    lib().ddc_pack_rx_frames(_np_ptr(s), _np_ptr(v), s.shape[0], _np_ptr(out))
+    return out
+
+
+def unpack_tx_frames(frames):
+    f = np.ascontiguousarray(frames, dtype=np.uint8)
+    n = f.size // 4
+    out = np.zeros((n, 2), np.int16)
+    lib().ddc_unpack_tx_frames(_np_ptr(f), n, _np_ptr(out))
+    return out
+
+
+def parse_params(b):
+    buf = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+    tx, pre, phi = C.c_int(), C.c_int(), C.c_uint32()
+    lib().ddc_parse_params(_np_ptr(buf), C.byref(tx), C.byref(pre), C.byref(phi))
+    return tx.value, pre.value, phi.value
