@@ -90,6 +90,14 @@ int ddc_sync(ddc_ctx *ctx);
 /* The HIP stream of the ctx (a hipStream_t), for callers that time or chain work. */
 void *ddc_stream(ddc_ctx *ctx);
 
+/* Timing taps (the reference's analogue is STM32/Src/profiler.c:21-88): when
+ * enabled, every ddc_rx_process_dev call records HIP events on the ctx stream
+ * around its ADC-ingest kernel and around the rest of the call.
+ * ddc_profile_collect waits for the stream and returns the summed durations in
+ * milliseconds of the (at most 256) calls since the last collect. */
+int ddc_profile_enable(ddc_ctx *ctx, int on);
+int ddc_profile_collect(ddc_ctx *ctx, double *front_ms, double *tail_ms, uint32_t *n_calls);
+
 /* Bus frames, byte-identical to the FPGA side of FPGA/stm32_interface.v.
  * ddc_pack_rx_frames: command 4 reply, 8 bytes per frame {SPEC_Q hi,lo, SPEC_I
  * hi,lo, VOICE_Q hi,lo, VOICE_I hi,lo} (:228-271).  ddc_unpack_tx_frames:

@@ -42,6 +42,12 @@ struct ddc_ctx {
     size_t out_cap = 0;
     std::vector<uint32_t> h_phi;
     ddc_tx_state tx;
+    // optional per-call timing: HIP events on the ctx stream around the front
+    // kernel and around the whole RX call
+    bool profile = false;
+    static constexpr int kProfRing = 256;
+    hipEvent_t ev[kProfRing][3] = {};
+    int prof_head = 0, prof_count = 0;
 };
 
 namespace {
@@ -217,6 +223,9 @@ void ddc_destroy(ddc_ctx *ctx)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     ddc_tx_state_destroy(&ctx->tx);
+    for (auto &e3 : ctx->ev)
+        for (auto &e : e3)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -337,13 +346,23 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     int rc = ensure_capacity(ctx, n_blk);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
+    hipEvent_t *pev = nullptr;
+    if (ctx->profile) {
+        pev = ctx->ev[ctx->prof_head];
+        if (!pev[0])
+            for (int k = 0; k < 3; k++) HIP_TRY(ctx, hipEventCreate(&pev[k]));
+        ctx->prof_head = (ctx->prof_head + 1) % ddc_ctx::kProfRing;
+        if (ctx->prof_count < ddc_ctx::kProfRing) ctx->prof_count++;
+    }
     ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp,
                                                  ctx->d_mom, ctx->d_cic, ctx->d_comp, n_blk);
     const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
     uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
+    if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
     ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
         adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
     ctx->carry_sel ^= 1;
+    if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
     ddc::ddc_rx_cic_combine<<<(total + 255) / 256, 256, 0, st>>>(ctx->d_mom, n_blk, nch, ctx->d_cic);
     const uint32_t nfr = nch * nf;
     ddc::ddc_rx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(ctx->d_cic, n_blk, nch, ctx->d_comp, spec_iq);
@@ -351,6 +370,7 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_mom,
                                                  ctx->d_cic, ctx->d_comp, ctx->d_acc, ctx->d_phi, n_blk,
                                                  (uint32_t)samples);
+    if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_blk = n_blk;
     return 0;
@@ -414,6 +434,36 @@ int ddc_sync(ddc_ctx *ctx)
 }
 
 void *ddc_stream(ddc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int ddc_profile_enable(ddc_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    ctx->profile = on != 0;
+    ctx->prof_head = 0;
+    ctx->prof_count = 0;
+    return 0;
+}
+
+int ddc_profile_collect(ddc_ctx *ctx, double *front_ms, double *tail_ms, uint32_t *n_calls)
+{
+    if (!ctx || !front_ms || !tail_ms || !n_calls) return -EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double f = 0, t = 0;
+    for (int i = 0; i < ctx->prof_count; i++) {
+        float a = 0, b = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[i][0], ctx->ev[i][1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[i][1], ctx->ev[i][2]));
+        f += a;
+        t += b;
+    }
+    *front_ms = f;
+    *tail_ms = t;
+    *n_calls = (uint32_t)ctx->prof_count;
+    ctx->prof_head = 0;
+    ctx->prof_count = 0;
+    return 0;
+}
 
 /* ---- bus frames -------------------------------------------------------- */
 

@@ -78,6 +78,8 @@ def lib():
     L.ddc_sync.argtypes = [vp]
     L.ddc_stream.argtypes = [vp]
     L.ddc_stream.restype = vp
+    L.ddc_profile_enable.argtypes = [vp, C.c_int]
+    L.ddc_profile_collect.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u32)]
     L.ddc_pack_rx_frames.argtypes = [vp, vp, sz, vp]
     L.ddc_pack_rx_frames.restype = None
     L.ddc_unpack_tx_frames.argtypes = [vp, sz, vp]
@@ -181,6 +183,15 @@ class Ddc:
 
     def sync(self):
         self._check(self._L.ddc_sync(self._h))
+
+    def profile_enable(self, on=True):
+        self._check(self._L.ddc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_collect(self):
+        """(front kernel ms summed, rest-of-call ms summed, calls)"""
+        f, t, n = C.c_double(), C.c_double(), C.c_uint32()
+        self._check(self._L.ddc_profile_collect(self._h, C.byref(f), C.byref(t), C.byref(n)))
+        return f.value, t.value, n.value
 
     def stream(self):
         return self._L.ddc_stream(self._h)
