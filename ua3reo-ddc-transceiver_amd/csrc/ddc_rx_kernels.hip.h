@@ -73,24 +73,56 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned w, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, w), c, false);
 }
 
-// One NCO + mixer step.  tab: 2048 coarse entries {2*sc | 2*cc<<16, 2*cc | (-2*sc)<<16}.
-// acc32 holds the 22-bit phase accumulator in its top 22 bits, so the natural
-// 32-bit wrap is the accumulator's wrap.  Returns the two 15-bit CIC inputs
-// wrap23(adc * nco12) >> 8.
-__device__ __forceinline__ void nco_mix(const uint2 *tab, uint32_t acc32, int adc, int &xi, int &xq)
+// v_dot2_i32_i16 with the addend in a scalar register (the compiler's own
+// choice, the accumulate-in-place VOP2 form, costs a v_mov per call to seed it).
+__device__ __forceinline__ int dot2_sconst(unsigned a, unsigned w, int c)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(w), "s"(c));
+    return r;
+}
+
+// NCO, first half: coarse-table fetch and the packed {8191, fine sine} operand.
+// tab: 2048 coarse entries {2*sc | 2*cc<<16, 2*cc | (-2*sc)<<16}.  acc32 holds
+// the 22-bit phase accumulator in its top 22 bits, so the natural 32-bit wrap is
+// the accumulator's wrap.
+__device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc32, uint2 &e, uint32_t &w)
 {
     const uint32_t off = (acc32 >> 18) & 0x3FF8u;
-    const uint2 e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off);
+    e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off);
     const uint32_t fi = __builtin_amdgcn_ubfe(acc32, 10, 11);
-    const uint32_t t = __umul24(fi, DDC_SF_K) + DDC_SF_R;          // t >> 24 = fine sine (0..25)
-    const uint32_t w = __builtin_amdgcn_perm(t, 0x1FFFu, 0x0C070100u); // {8191, t>>24}
-    // 2*(sc*8191 + cc*sf + 4096): the 14-bit output's top 12 bits are bits 31..16
-    const int s = dot2(e.x, w, 8192);
-    const int c = dot2(e.y, w, 8192);
+    const uint32_t t = __umul24(fi, DDC_SF_K) + DDC_SF_R;     // t >> 24 = fine sine (0..25)
+    w = __builtin_amdgcn_perm(t, 0x1FFFu, 0x0C070100u);       // {8191, t>>24}
+}
+
+// NCO second half + mixer: 2*(sc*8191 + cc*sf + 4096) has the 12-bit mixer
+// operand (14-bit output >> 2) in bits 31..16.  Returns the two 15-bit CIC
+// inputs wrap23(adc * nco12) >> 8.
+__device__ __forceinline__ void nco_finish(const uint2 e, uint32_t w, int adc, int &xi, int &xq)
+{
+    const int s = dot2_sconst(e.x, w, 8192);
+    const int c = dot2_sconst(e.y, w, 8192);
     const int pi = __mul24(adc, s >> 16);
     const int pq = __mul24(adc, c >> 16);
     xi = __builtin_amdgcn_sbfe(pi, 8, 15);
     xq = __builtin_amdgcn_sbfe(pq, 8, 15);
+}
+
+__device__ __forceinline__ void nco_mix(const uint2 *tab, uint32_t acc32, int adc, int &xi, int &xq)
+{
+    uint2 e;
+    uint32_t w;
+    nco_fetch(tab, acc32, e, w);
+    nco_finish(e, w, adc, xi, xq);
+}
+
+// 16 bytes per lane from global memory straight into LDS (no VGPR round trip):
+// lane l of the wave lands at lds_wave_base + 16 l.
+__device__ __forceinline__ void lds_dma16(const uint8_t *g, uint4 *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)g,
+        (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
 __device__ __forceinline__ unsigned pack16(int lo, int hi)
@@ -188,14 +220,20 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
 {
     int a[8];
     unpack8(d0, d1, d2, a);
+    uint2 e[8];
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) nco_fetch(tab, acc32 + (uint32_t)k * phi32, e[k], w[k]);
+    acc32 += 8u * phi32;
+    // keep the running phase opaque: otherwise all 32 multiples of phi32 of a
+    // chunk are hoisted into registers of their own
+    asm volatile("" : "+v"(acc32));
     unsigned pi[4], pq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int xi0, xq0, xi1, xq1;
-        nco_mix(tab, acc32, a[2 * k], xi0, xq0);
-        acc32 += phi32;
-        nco_mix(tab, acc32, a[2 * k + 1], xi1, xq1);
-        acc32 += phi32;
+        nco_finish(e[2 * k], w[2 * k], a[2 * k], xi0, xq0);
+        nco_finish(e[2 * k + 1], w[2 * k + 1], a[2 * k + 1], xi1, xq1);
         pi[k] = pack16(xi0, xi1);
         pq[k] = pack16(xq0, xq1);
     }
@@ -252,9 +290,9 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     const uint32_t phi32 = phi32v[ch];
     uint32_t acc32 = acc0[ch] + (b * (uint32_t)kBlk) * phi32;
 
-    uint4 pre[3];
+    const uint32_t wave_base = tid & ~63u;
 #pragma unroll
-    for (int j = 0; j < 3; j++) pre[j] = *reinterpret_cast<const uint4 *>(src[j]);
+    for (int j = 0; j < 3; j++) lds_dma16(src[j], &stage[0][wave_base + kFrontThreads * j]);
 
     Cascade ci, cq;
     ci.clear();
@@ -295,8 +333,7 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
         cq.step(mq);
     }
 
-#pragma unroll
-    for (int j = 0; j < 3; j++) stage[0][tid + kFrontThreads * j] = pre[j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     unsigned last_i[3] = {0, 0, 0}, last_q[3] = {0, 0, 0};
@@ -305,7 +342,7 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
         if (a + 1 < kChunksPerBlk) {
 #pragma unroll
             for (int j = 0; j < 3; j++)
-                pre[j] = *reinterpret_cast<const uint4 *>(src[j] + (a + 1) * kChunkBytes);
+                lds_dma16(src[j] + (a + 1) * kChunkBytes, &stage[(a + 1) & 1][wave_base + kFrontThreads * j]);
         }
         const uint4 *mine = &stage[a & 1][3 * tid];
         const uint4 v0 = mine[0], v1 = mine[1], v2 = mine[2];
@@ -321,8 +358,7 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
         ci.step(mi);
         cq.step(mq);
         if (a + 1 < kChunksPerBlk) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) stage[(a + 1) & 1][tid + kFrontThreads * j] = pre[j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }

@@ -11,7 +11,7 @@ import numpy as np
 
 DECIMATION = 1024
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_PKG, "libua3reo_ddc.so")
+_SO = os.environ.get("UA3REO_DDC_LIB") or os.path.join(_PKG, "libua3reo_ddc.so")
 _CSRC = os.path.join(_PKG, "csrc")
 
 
