@@ -85,6 +85,24 @@ int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t 
  * [channel][samples/512][2] int16 (host pointer). */
 int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples);
 
+/* TX: 48 kHz I/Q -> DAC words at 1024x the rate.
+ * Replaces the FPGA TX datapath tx_ciccomp.vhd + tx_cic.vhd + tx_mixer.v +
+ * tx_summator.v + DAC_corrector.v as wired in FPGA/UA3REO.bdf, fed by command 3
+ * of the bus (FPGA/stm32_interface.v:206-227 <- FPGA_fpgadata_sendiq,
+ * STM32/Src/fpga.c:403-466) and driving DAC_OUTPUT[13..0].
+ *
+ *   iq48k   [channel][n_iq][2] int16: TX_I, TX_Q, one pair per 48 kHz tick
+ *   dac14   [channel][1024 * n_iq] uint16: 14-bit offset-binary DAC words
+ *           (8191 = mid scale), DAC word t of the call at index t
+ * The carrier is the channel's tuning word (ddc_tune); state carries over from
+ * call to call.  The reference's DAC_OTR flag (adder overflow) can never rise:
+ * |tx_cic| <= 8192 and |NCO| <= 8191 keep the 28-bit sum in range. */
+int ddc_tx_process_dev(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t *dac14);
+int ddc_tx_process(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t *dac14);
+/* Zero the TX datapath state (reset = TX_N on every RX->TX switch). */
+int ddc_tx_reset(ddc_ctx *ctx, int32_t channel);
+int ddc_tx_set_phase(ddc_ctx *ctx, int32_t channel, uint32_t phase22);
+
 /* Wait for everything queued on the ctx stream. */
 int ddc_sync(ddc_ctx *ctx);
 /* The HIP stream of the ctx (a hipStream_t), for callers that time or chain work. */

@@ -220,3 +220,88 @@ def parse_params(b):
     tx, pre, f = C.c_int(), C.c_int(), C.c_uint32()
     lib().orc_parse_params(buf, C.byref(tx), C.byref(pre), C.byref(f))
     return tx.value, pre.value, f.value
+
+
+# ------------------------------------------------------------------ TX ----
+def _tx_proto():
+    L = lib()
+    L.orc_tx_ciccomp_sizeof.restype = C.c_size_t
+    L.orc_tx_back_sizeof.restype = C.c_size_t
+    L.orc_tx_chain_sizeof.restype = C.c_size_t
+    L.orc_tx_ciccomp_run.restype = C.c_size_t
+    L.orc_tx_ciccomp_cycle.restype = C.c_size_t
+    L.orc_tx_back_run.restype = C.c_size_t
+    L.orc_tx_chain_run.restype = C.c_size_t
+    return L
+
+
+class TxCicComp(_State):
+    _size, _reset = "orc_tx_ciccomp_sizeof", "orc_tx_ciccomp_reset"
+
+    def __init__(self):
+        _tx_proto()
+        super().__init__()
+
+    def run(self, x):
+        x = _i16(x)
+        out = np.zeros(2 * x.size, np.int16)
+        lib().orc_tx_ciccomp_run(self.buf, _p(x), C.c_size_t(x.size), _p(out))
+        return out
+
+
+def tx_ciccomp_cycle(x):
+    _tx_proto()
+    x = _i16(x)
+    out = np.zeros(2 * x.size + 4, np.int16)
+    k = lib().orc_tx_ciccomp_cycle(_p(x), C.c_size_t(x.size), _p(out), C.c_size_t(out.size))
+    return out[:min(k, out.size)].copy()
+
+
+class TxBack(_State):
+    """tx_cic + tx_mixer + tx_summator + DAC_corrector, clock-edge model."""
+    _size, _reset = "orc_tx_back_sizeof", "orc_tx_back_reset"
+
+    def __init__(self, phi):
+        _tx_proto()
+        super().__init__(C.c_uint32(int(phi)))
+
+    def set_phase(self, acc):
+        lib().orc_tx_back_set_phase(self.buf, C.c_uint32(int(acc)))
+
+    def run(self, yi, yq, want_cic=False):
+        yi, yq = _i16(yi), _i16(yq)
+        n = yi.size
+        dac = np.zeros(512 * n, np.uint16)
+        ci = np.zeros(512 * n, np.int16) if want_cic else None
+        cq = np.zeros(512 * n, np.int16) if want_cic else None
+        lib().orc_tx_back_run(self.buf, _p(yi), _p(yq), C.c_size_t(n), _p(dac),
+                              _p(ci) if want_cic else None, _p(cq) if want_cic else None)
+        return (dac, ci, cq) if want_cic else dac
+
+    def overflow(self):
+        return bool(lib().orc_tx_back_overflow(self.buf))
+
+
+class TxChain(_State):
+    """Whole FPGA TX side for one channel: 48 kHz I/Q -> DAC words."""
+    _size, _reset = "orc_tx_chain_sizeof", "orc_tx_chain_reset"
+
+    def __init__(self, phi):
+        _tx_proto()
+        super().__init__(C.c_uint32(int(phi)))
+
+    def tune(self, phi):
+        lib().orc_tx_chain_tune(self.buf, C.c_uint32(int(phi)))
+
+    def set_phase(self, acc):
+        lib().orc_tx_chain_set_phase(self.buf, C.c_uint32(int(acc)))
+
+    def run(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+        n = iq.shape[0]
+        dac = np.zeros(1024 * n, np.uint16)
+        lib().orc_tx_chain_run(self.buf, _p(iq), C.c_size_t(n), _p(dac))
+        return dac
+
+    def overflow(self):
+        return bool(lib().orc_tx_chain_overflow(self.buf))

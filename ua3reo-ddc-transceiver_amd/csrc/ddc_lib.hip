@@ -425,6 +425,93 @@ int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples)
     return 0;
 }
 
+/* ---- TX ---------------------------------------------------------------- */
+
+int ddc_tx_reset(ddc_ctx *ctx, int32_t channel)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t lo = channel < 0 ? 0 : (size_t)channel;
+    const size_t n = channel < 0 ? ctx->cfg.n_channels : 1;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->tx.d_acc + lo, 0, n * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->tx.d_hist_x + lo * ddc::kTxXHist * 2, 0, n * ddc::kTxXHist * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->tx.d_hist_y + lo * ddc::kTxYHist * 2, 0, n * ddc::kTxYHist * 4, ctx->stream));
+    return 0;
+}
+
+int ddc_tx_set_phase(ddc_ctx *ctx, int32_t channel, uint32_t phase22)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0) return fail(ctx, -EINVAL, "ddc_tx_set_phase needs one channel");
+    const uint32_t v = (phase22 & 0x3FFFFF) << 10;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tx.d_acc + channel, &v, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_tx_process_dev(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t *dac14)
+{
+    if (!ctx) return -EINVAL;
+    if (n_iq == 0) return 0;
+    if (!iq48k || !dac14) return fail(ctx, -EINVAL, "null buffer");
+    if (((uintptr_t)dac14 % 16) || ((uintptr_t)iq48k % 4)) return fail(ctx, -EINVAL, "TX buffers must be 16-byte (DAC) / 4-byte (I/Q) aligned");
+    const uint64_t nch = ctx->cfg.n_channels;
+    if (n_iq > (1u << 21) || nch * (2 * n_iq + 1) >= (1ull << 31))
+        return fail(ctx, -EINVAL, "too many TX samples in one call");
+    const uint32_t n48 = (uint32_t)n_iq, n96 = 2 * n48;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ddc_tx_state &tx = ctx->tx;
+    if (n48 > tx.cap48) {
+        if (tx.d_ybuf) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(tx.d_ybuf); }
+        tx.d_ybuf = nullptr; tx.cap48 = 0;
+        HIP_TRY(ctx, hipMalloc(&tx.d_ybuf, nch * (ddc::kTxYHist + (size_t)n96) * 4));
+        tx.cap48 = n48;
+    }
+    hipStream_t st = ctx->stream;
+    ddc::ddc_tx_load_history<<<(uint32_t)nch, 64, 0, st>>>(tx.d_hist_y, tx.d_ybuf, n96);
+    const uint32_t nfr = (uint32_t)(nch * n48);
+    ddc::ddc_tx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(iq48k, tx.d_hist_x, n48, (uint32_t)nch, tx.d_ybuf);
+    const uint32_t total = (uint32_t)(nch * (n96 + 1));
+    ddc::ddc_tx_duc<<<(total + 255) / 256, 256, 0, st>>>(tx.d_ybuf, n96, total, tx.d_acc, ctx->d_phi, dac14,
+                                                        ctx->d_nco_tab);
+    ddc::ddc_tx_save_history<<<(uint32_t)nch, 64, 0, st>>>(tx.d_hist_x, tx.d_hist_y, iq48k, tx.d_ybuf, tx.d_acc,
+                                                        ctx->d_phi, n48);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ddc_tx_process(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t *dac14)
+{
+    if (!ctx) return -EINVAL;
+    if (n_iq == 0) return 0;
+    if (!iq48k || !dac14) return fail(ctx, -EINVAL, "null buffer");
+    const size_t nch = ctx->cfg.n_channels;
+    const size_t in_elems = nch * n_iq * 2, out_elems = nch * n_iq * 1024;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ddc_tx_state &tx = ctx->tx;
+    if (in_elems > tx.in_cap) {
+        if (tx.d_in) (void)hipFree(tx.d_in);
+        tx.d_in = nullptr; tx.in_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&tx.d_in, in_elems * sizeof(int16_t)));
+        tx.in_cap = in_elems;
+    }
+    if (out_elems > tx.out_cap) {
+        if (tx.d_out) (void)hipFree(tx.d_out);
+        tx.d_out = nullptr; tx.out_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&tx.d_out, out_elems * sizeof(uint16_t)));
+        tx.out_cap = out_elems;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(tx.d_in, iq48k, in_elems * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+    int rc = ddc_tx_process_dev(ctx, tx.d_in, n_iq, tx.d_out);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dac14, tx.d_out, out_elems * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int ddc_sync(ddc_ctx *ctx)
 {
     if (!ctx) return -EINVAL;

@@ -75,6 +75,10 @@ def lib():
     L.ddc_rx_process_dev.argtypes = [vp, vp, sz, sz, vp, vp]
     L.ddc_rx_process.argtypes = [vp, vp, sz, sz, vp, vp]
     L.ddc_rx_read_cic.argtypes = [vp, vp, sz]
+    L.ddc_tx_process_dev.argtypes = [vp, vp, sz, vp]
+    L.ddc_tx_process.argtypes = [vp, vp, sz, vp]
+    L.ddc_tx_reset.argtypes = [vp, i32]
+    L.ddc_tx_set_phase.argtypes = [vp, i32, u32]
     L.ddc_sync.argtypes = [vp]
     L.ddc_stream.argtypes = [vp]
     L.ddc_stream.restype = vp
@@ -180,6 +184,24 @@ class Ddc:
         out = np.zeros((self.n_channels, samples // 512, 2), np.int16)
         self._check(self._L.ddc_rx_read_cic(self._h, _np_ptr(out), samples))
         return out
+
+    def tx_process(self, iq48k):
+        """Host path. iq48k: int16 [n_channels][n][2]; returns uint16 [n_channels][1024 n]."""
+        a = np.ascontiguousarray(iq48k, dtype=np.int16)
+        assert a.ndim == 3 and a.shape[0] == self.n_channels and a.shape[2] == 2
+        n = a.shape[1]
+        dac = np.zeros((self.n_channels, 1024 * n), np.uint16)
+        self._check(self._L.ddc_tx_process(self._h, _np_ptr(a), n, _np_ptr(dac)))
+        return dac
+
+    def tx_process_dev(self, iq_ptr, n_iq, dac_ptr):
+        self._check(self._L.ddc_tx_process_dev(self._h, iq_ptr, n_iq, dac_ptr))
+
+    def tx_reset(self, channel=-1):
+        self._check(self._L.ddc_tx_reset(self._h, channel))
+
+    def tx_set_phase(self, channel, phase):
+        self._check(self._L.ddc_tx_set_phase(self._h, channel, int(phase)))
 
     def sync(self):
         self._check(self._L.ddc_sync(self._h))
