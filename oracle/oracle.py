@@ -14,8 +14,8 @@ _SO = os.path.join(_HERE, "libddc_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "ddc_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ddc_oracle.c", "audio_oracle.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return _SO
 
@@ -305,3 +305,62 @@ class TxChain(_State):
 
     def overflow(self):
         return bool(lib().orc_tx_chain_overflow(self.buf))
+
+
+# --------------------------------------------------------------- audio ----
+MODES = {"LSB": 0, "USB": 1, "IQ": 2, "CW_L": 3, "CW_U": 4, "DIGI_L": 5, "DIGI_U": 6, "NO_TX": 7,
+         "NFM": 8, "WFM": 9, "AM": 10, "LOOPBACK": 11}
+
+
+class AudioParams(C.Structure):
+    _fields_ = [("mode", C.c_uint8), ("agc", C.c_uint8), ("dnr", C.c_uint8), ("notch", C.c_uint8),
+                ("mute", C.c_uint8), ("cw_decoder", C.c_uint8), ("fm_sql_threshold", C.c_uint8),
+                ("volume", C.c_uint8), ("iq_swap", C.c_uint8), ("fft_averaging", C.c_uint8),
+                ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("filter_width", C.c_uint16),
+                ("hpf_pass", C.c_uint16), ("notch_fc", C.c_uint16), ("agc_speed", C.c_uint16),
+                ("rf_gain", C.c_float)]
+
+
+def audio_params(mode="USB", agc=1, dnr=0, notch=0, mute=0, cw_decoder=0, fm_sql_threshold=0, volume=50,
+                 iq_swap=0, fft_averaging=4, filter_width=2700, hpf_pass=300, notch_fc=1000, agc_speed=3,
+                 rf_gain=50.0):
+    return AudioParams(MODES[mode] if isinstance(mode, str) else mode, agc, dnr, notch, mute, cw_decoder,
+                       fm_sql_threshold, volume, iq_swap, fft_averaging, 0, 0, filter_width, hpf_pass,
+                       notch_fc, agc_speed, rf_gain)
+
+
+class Audio:
+    """STM32 RX audio path + FFT panadapter of one channel."""
+
+    def __init__(self, params):
+        L = lib()
+        L.orc_audio_sizeof.restype = C.c_size_t
+        self.buf = C.create_string_buffer(L.orc_audio_sizeof())
+        if L.orc_audio_configure(self.buf, C.byref(params)) != 0:
+            raise ValueError("unsupported filter selection")
+
+    def rx(self, spec_iq, voice_iq):
+        spec = np.ascontiguousarray(spec_iq, dtype=np.int16).reshape(-1, 2)
+        voice = np.ascontiguousarray(voice_iq, dtype=np.int16).reshape(-1, 2)
+        n = spec.shape[0]
+        assert n % 192 == 0 and voice.shape[0] == n
+        out = np.zeros((n, 2), np.int32)
+        lib().orc_audio_rx_run(self.buf, _p(spec), _p(voice), C.c_size_t(n), _p(out))
+        return out
+
+    def status(self):
+        mx, mn, g = C.c_float(), C.c_float(), C.c_float()
+        text = C.create_string_buffer(16)
+        wpm, sq = C.c_uint16(), C.c_int()
+        lib().orc_audio_status(self.buf, C.byref(mx), C.byref(mn), C.byref(g), text, C.byref(wpm), C.byref(sq))
+        return {"smeter_max": mx.value, "smeter_min": mn.value, "agc_gain": g.value,
+                "cw_text": text.value.decode("ascii", "replace"), "cw_wpm": wpm.value, "squelched": bool(sq.value)}
+
+    def fft(self, spec_iq):
+        spec = np.ascontiguousarray(spec_iq, dtype=np.int16).reshape(-1, 2)
+        assert spec.shape[0] == 512
+        bins = np.zeros(256, np.float32)
+        row = np.zeros(256, np.uint16)
+        hts = np.zeros(256, np.uint8)
+        lib().orc_fft_frame(self.buf, _p(spec), _p(bins), _p(row), _p(hts))
+        return bins, row, hts

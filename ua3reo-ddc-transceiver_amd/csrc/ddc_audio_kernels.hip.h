@@ -1,0 +1,545 @@
+/*
+ * 48 kHz RX audio path and FFT panadapter of the MI355X DDC.
+ *
+ * Replaces the STM32-side processing of the reference (float32, CMSIS-DSP):
+ *   dc_filter                      STM32/Src/audio_filters.c:358-373
+ *   doRX_HPF / doRX_LPF            STM32/Src/audio_processor.c:445-464 (arm_iir_lattice_f32,
+ *                                  tables audio_filters.c:45-122, selection :141-339)
+ *   SSB / AM / FM demodulation     STM32/Src/audio_processor.c:308-362, :509-588
+ *   doRX_NOTCH + calcBiquad        STM32/Src/audio_processor.c:466-473, audio_filters.c:375-494
+ *   processNoiseReduction          STM32/Src/noise_reduction.c:19-37 (arm_lms_norm_f32)
+ *   DoAGC                          STM32/Src/agc.c:21-67
+ *   CWDecoder_Process              STM32/Src/cw_decoder.c:56-174 (millisecond clock = 4 ms per block)
+ *   output stage                   STM32/Src/audio_processor.c:364-394
+ *   FFT_doFFT + row mapping        STM32/Src/fft.c:212-331, :361-379, :506-539
+ *
+ * All of it is recursion in time (IIR lattices, LMS, AGC, squelch), so the only
+ * parallel axis is the channel: one thread walks one channel, block by block of
+ * 192 frames, exactly in the firmware's order of operations.  Floating-point
+ * contraction is off so that every operation rounds where the firmware's does.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ua3reo_ddc.h"
+#include "ddc_audio_coeffs.h"
+
+namespace ddc {
+
+#pragma clang fp contract(off)
+
+constexpr int kABlock = 192;
+constexpr int kASub = 64;
+constexpr float kPiF = 3.14159265358979f;
+
+struct Lattice {
+    float g[12];
+};
+
+struct AudioState {
+    ddc_audio_params p;
+    int32_t lpf_idx, hpf_idx, lpf_n, pad;
+    float dc_x[6], dc_y[6];
+    Lattice lpf_i, lpf_q, hpf_i, hpf_q;
+    float notch_c[5];
+    float notch_d[2], notch_fi[2], notch_fq[2];
+    float lms_w[16], lms_hist[15], lms_energy, lms_x0;
+    float lms_ref[128];
+    uint32_t ref_old, ref_new;
+    float agc_gain, agc_gain_old, agc_up, agc_down;
+    float fm_lpf_prev, fm_hpf_a, fm_hpf_b, fm_i_prev, fm_q_prev, fm_sql_avg;
+    uint32_t fm_sql_count, squelched;
+    float smeter_max, smeter_min;
+    float cw_coeff, cw_limit, cw_limit_low;
+    uint32_t cw_real, cw_real_before, cw_filt, cw_filt_before, cw_stop;
+    int64_t cw_laststart, cw_starthigh, cw_highdur, cw_startlow, cw_lowdur, cw_highavg;
+    uint32_t cw_wpm;
+    char cw_code[20], cw_text[16];
+    uint32_t blocks;
+    float fft_mean[256], fft_max_value;
+    uint32_t fft_max_errors;
+};
+
+__device__ __forceinline__ void lattice_step(Lattice &s, int n, const float *k, const float *v, float &x)
+{
+    float fcurr = x, fnext = x, acc = 0.0f, ng[12];
+    for (int i = 0; i < n; i++) {
+        const float gcurr = s.g[i];
+        fnext = fcurr - k[i] * gcurr;
+        const float gnext = fnext * k[i] + gcurr;
+        acc += gnext * v[i];
+        ng[i] = gnext;
+        fcurr = fnext;
+    }
+    acc += fnext * v[n];
+    for (int i = 0; i + 1 < n; i++) s.g[i] = ng[i + 1];
+    s.g[n - 1] = fnext;
+    x = acc;
+}
+
+__device__ __forceinline__ float dc_step(AudioState &s, int slot, float in)
+{
+    const float A1 = 0.99951171875f; // 1 - 2^-11
+    const float delta = in - s.dc_x[slot];
+    const float a1y = A1 * s.dc_y[slot];
+    const float out = delta + a1y;
+    s.dc_x[slot] = in;
+    s.dc_y[slot] = out;
+    return out;
+}
+
+__device__ __forceinline__ float biquad_step(const float *c, float *d, float x)
+{
+    const float acc = c[0] * x + d[0];
+    d[0] = (c[1] * x + c[3] * acc) + d[1];
+    d[1] = c[2] * x + c[4] * acc;
+    return acc;
+}
+
+__device__ inline void lms_block(AudioState &s, float *x /*64, in place*/)
+{
+    float st[15 + kASub];
+    for (int i = 0; i < 15; i++) st[i] = s.lms_hist[i];
+    const float *ref = &s.lms_ref[s.ref_old];
+    float energy = s.lms_energy, x0 = s.lms_x0;
+    for (int t = 0; t < kASub; t++) {
+        const float in = x[t];
+        st[15 + t] = in;
+        const float *px = st + t;
+        energy -= x0 * x0;
+        energy += in * in;
+        float acc = 0.0f;
+        for (int i = 0; i < 16; i++) acc += px[i] * s.lms_w[i];
+        const float e = ref[t] - acc;
+        const float w = (e * 0.000001f) / (energy + 0.000000119209289f);
+        for (int i = 0; i < 16; i++) s.lms_w[i] += w * px[i];
+        x0 = px[0];
+        x[t] = acc;
+    }
+    s.lms_energy = energy;
+    s.lms_x0 = x0;
+    for (int i = 0; i < 15; i++) s.lms_hist[i] = st[kASub + i];
+}
+
+__device__ inline void agc_block(AudioState &s, float *buf)
+{
+    float mx = buf[0];
+    for (int i = 1; i < kABlock; i++) if (buf[i] > mx) mx = buf[i];
+    if (mx == 0.0f) mx = 0.001f;
+    const float target = 7000 / mx;
+    if (target > s.agc_gain) {
+        float step = (target - s.agc_gain) / s.agc_up;
+        if (step > 1.0f) step = 1.0f;
+        s.agc_gain += step;
+    } else
+        s.agc_gain -= (s.agc_gain - target) / s.agc_down;
+    if (s.agc_gain < 0.0f) s.agc_gain = 0.0f;
+    if ((s.agc_gain * mx) > 10000) s.agc_gain = target;
+    const int m = s.p.mode;
+    if (!s.p.agc || m == DDC_MODE_DIGI_L || m == DDC_MODE_DIGI_U) s.agc_gain = 1.0f;
+    if (s.agc_gain_old != s.agc_gain) {
+        float step = 0;
+        if (s.agc_gain_old > s.agc_gain) step = -(s.agc_gain_old - s.agc_gain) / kABlock;
+        if (s.agc_gain_old < s.agc_gain) step = (s.agc_gain - s.agc_gain_old) / kABlock;
+        for (int i = 0; i < kABlock; i++) {
+            s.agc_gain_old += step;
+            buf[i] = buf[i] * s.agc_gain_old;
+        }
+    } else
+        for (int i = 0; i < kABlock; i++) buf[i] = buf[i] * s.agc_gain;
+}
+
+__device__ inline void fm_block(AudioState &s, float *bi, const float *bq)
+{
+    float first_angle = 0;
+    for (int i = 0; i < kABlock; i++) {
+        const float y = (bq[i] * s.fm_i_prev) - (bi[i] * s.fm_q_prev);
+        const float x = (bi[i] * s.fm_i_prev) + (bq[i] * s.fm_q_prev);
+        const float angle = atan2f(y, x);
+        if (i == 0) first_angle = angle;
+        const float a = s.fm_lpf_prev + (0.05f * (angle - s.fm_lpf_prev));
+        s.fm_lpf_prev = a;
+        s.fm_q_prev = bq[i];
+        s.fm_i_prev = bi[i];
+        if (!s.squelched || !s.p.fm_sql_threshold) {
+            if (s.p.mode == DDC_MODE_WFM)
+                bi[i] = angle / kPiF * 16384.0f;
+            else {
+                const float b = 0.96f * (s.fm_hpf_b + a - s.fm_hpf_a);
+                s.fm_hpf_a = a;
+                s.fm_hpf_b = b;
+                bi[i] = b * 30000.0f;
+            }
+        } else
+            bi[i] = 0;
+    }
+    s.fm_sql_avg = ((1.0f - 0.005f) * s.fm_sql_avg) + (0.005f * sqrtf(fabsf(first_angle)));
+    if (s.fm_sql_count == 0) {
+        if (s.fm_sql_avg > 0.7f) s.fm_sql_avg = 0.7f;
+        const float b = s.fm_sql_avg * 10.0f;
+        const int thr = s.p.fm_sql_threshold;
+        if (!thr) s.squelched = 0;
+        else if (s.squelched) {
+            if (b <= (float)((10 - thr) - 0.3f)) s.squelched = 0;
+        } else {
+            if ((10.0f - thr) > 0.3f) {
+                if (b > (float)((10 - thr) + 0.3f)) s.squelched = 1;
+            } else if (b > (10.0f - (float)thr)) s.squelched = 1;
+        }
+        s.fm_sql_count++; // only ever bumped here, as in the firmware
+        if (s.fm_sql_count >= 50) s.fm_sql_count = 0;
+    }
+}
+
+__device__ inline int dev_strlen(const char *s) { int n = 0; while (s[n]) n++; return n; }
+
+__device__ inline void cw_print(AudioState &s, char c)
+{
+    int n = dev_strlen(s.cw_text);
+    if (n >= 15) {
+        for (int i = 0; i < 15; i++) s.cw_text[i] = s.cw_text[i + 1];
+        n = dev_strlen(s.cw_text);
+    }
+    s.cw_text[n] = c;
+    s.cw_text[n + 1] = 0;
+}
+
+// Morse table as (length, bit pattern: 1 = dash, first symbol in the highest used bit)
+__device__ inline void cw_decode(AudioState &s)
+{
+    const int n = dev_strlen(s.cw_code);
+    if (n == 0 || n > 7) return;
+    unsigned pat = 0;
+    for (int i = 0; i < n; i++) pat = (pat << 1) | (s.cw_code[i] == '-' ? 1u : 0u);
+    const unsigned key = ((unsigned)n << 8) | pat;
+    char c = 0;
+    switch (key) {
+    case 0x201: c = 'A'; break; case 0x408: c = 'B'; break; case 0x40A: c = 'C'; break; case 0x304: c = 'D'; break;
+    case 0x100: c = 'E'; break; case 0x402: c = 'F'; break; case 0x306: c = 'G'; break; case 0x400: c = 'H'; break;
+    case 0x200: c = 'I'; break; case 0x407: c = 'J'; break; case 0x305: c = 'K'; break; case 0x404: c = 'L'; break;
+    case 0x203: c = 'M'; break; case 0x202: c = 'N'; break; case 0x307: c = 'O'; break; case 0x406: c = 'P'; break;
+    case 0x40D: c = 'Q'; break; case 0x302: c = 'R'; break; case 0x300: c = 'S'; break; case 0x101: c = 'T'; break;
+    case 0x301: c = 'U'; break; case 0x401: c = 'V'; break; case 0x303: c = 'W'; break; case 0x409: c = 'X'; break;
+    case 0x40B: c = 'Y'; break; case 0x40C: c = 'Z'; break;
+    case 0x50F: c = '1'; break; case 0x507: c = '2'; break; case 0x503: c = '3'; break; case 0x501: c = '4'; break;
+    case 0x500: c = '5'; break; case 0x510: c = '6'; break; case 0x518: c = '7'; break; case 0x51C: c = '8'; break;
+    case 0x51E: c = '9'; break; case 0x51F: c = '0'; break;
+    case 0x60C: c = '?'; break; case 0x615: c = '.'; break; case 0x633: c = ','; break; case 0x62B: c = '!'; break;
+    case 0x61A: c = '@'; break; case 0x638: c = ':'; break; case 0x621: c = '-'; break; case 0x512: c = '/'; break;
+    case 0x516: c = '('; break; case 0x62D: c = ')'; break; case 0x508: c = '_'; break; case 0x709: c = '$'; break;
+    case 0x605: c = '>'; break; case 0x50A: c = '<'; break; case 0x502: c = '~'; break;
+    default: break;
+    }
+    if (c) cw_print(s, c);
+}
+
+__device__ inline void cw_append(AudioState &s, char c)
+{
+    const int n = dev_strlen(s.cw_code);
+    if (n < 19) { s.cw_code[n] = c; s.cw_code[n + 1] = 0; }
+}
+
+__device__ inline void cw_block(AudioState &s, const float *buf, int64_t now_ms)
+{
+    float q1 = 0, q2 = 0;
+    for (int i = 0; i < kABlock; i++) {
+        const float q0 = s.cw_coeff * q1 - q2 + buf[i];
+        q2 = q1;
+        q1 = q0;
+    }
+    const float mag2 = (q1 * q1) + (q2 * q2) - q1 * q2 * s.cw_coeff;
+    const float magnitude = (float)sqrt((double)mag2);
+    if (magnitude > s.cw_limit_low) s.cw_limit = (s.cw_limit + ((magnitude - s.cw_limit) / 100));
+    s.cw_limit_low = (s.cw_limit_low + ((magnitude - s.cw_limit_low) / 1000));
+    if (s.cw_limit_low > magnitude) s.cw_limit_low = magnitude;
+    s.cw_real = magnitude > (s.cw_limit_low + (s.cw_limit - s.cw_limit_low) * 0.8f);
+    if (s.cw_real != s.cw_real_before) s.cw_laststart = now_ms;
+    if ((now_ms - s.cw_laststart) > 6)
+        if (s.cw_real != s.cw_filt) s.cw_filt = s.cw_real;
+    if (s.cw_filt != s.cw_filt_before) {
+        if (s.cw_filt) {
+            s.cw_starthigh = now_ms;
+            s.cw_lowdur = now_ms - s.cw_startlow;
+        } else {
+            s.cw_startlow = now_ms;
+            s.cw_highdur = now_ms - s.cw_starthigh;
+            if (s.cw_highdur < (2 * s.cw_highavg) || s.cw_highavg == 0)
+                s.cw_highavg = (s.cw_highdur + s.cw_highavg + s.cw_highavg) / 3;
+            if (s.cw_highdur > (5 * s.cw_highavg)) s.cw_highavg = s.cw_highdur + s.cw_highavg;
+        }
+        s.cw_stop = 0;
+        if (!s.cw_filt) {
+            if ((double)s.cw_highdur < (double)(s.cw_highavg * 2) && (double)s.cw_highdur > (s.cw_highavg * 0.6)) cw_append(s, '.');
+            if (s.cw_highdur > (s.cw_highavg * 2) && s.cw_highdur < (s.cw_highavg * 6)) {
+                cw_append(s, '-');
+                s.cw_wpm = (uint32_t)(uint16_t)((s.cw_wpm + (1200 / ((s.cw_highdur) / 3))) / 2);
+            }
+        } else {
+            float lack = 1.0f;
+            if (s.cw_wpm > 30) lack = 1.2f;
+            if (s.cw_wpm > 35) lack = 1.5f;
+            if ((float)s.cw_lowdur > ((float)s.cw_highavg * (2 * lack)) && (float)s.cw_lowdur < (float)s.cw_highavg * (5 * lack)) {
+                cw_decode(s);
+                s.cw_code[0] = 0;
+            }
+            if ((float)s.cw_lowdur >= (float)s.cw_highavg * (5 * lack)) {
+                cw_decode(s);
+                s.cw_code[0] = 0;
+                cw_print(s, ' ');
+            }
+        }
+    }
+    if ((now_ms - s.cw_startlow) > (s.cw_highdur * 6) && !s.cw_stop) {
+        cw_decode(s);
+        s.cw_code[0] = 0;
+        s.cw_stop = 1;
+    }
+    s.cw_real_before = s.cw_real;
+    s.cw_filt_before = s.cw_filt;
+}
+
+__device__ __forceinline__ int32_t f2i_sat(float v)
+{
+    if (!(v == v)) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)v;
+}
+
+/*
+ * processRxAudio for every channel: thread = channel, sequential over the
+ * n_frames / 192 blocks of the call.  spec_iq / voice_iq: [channel][n_frames][2]
+ * int16; audio: [channel][n_frames][2] int32 (left = I, right = Q).
+ */
+__global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ states, uint32_t n_ch,
+                                                   const int16_t *__restrict__ spec_iq,
+                                                   const int16_t *__restrict__ voice_iq, uint32_t n_frames,
+                                                   int32_t *__restrict__ audio)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_ch) return;
+    AudioState s = states[ch];
+    const int m = s.p.mode;
+    const bool use_spec = (m == DDC_MODE_IQ || m == DDC_MODE_NFM || m == DDC_MODE_WFM || m == DDC_MODE_AM);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(use_spec ? spec_iq : voice_iq) + (size_t)ch * n_frames;
+    int32_t *dst = audio + (size_t)ch * n_frames * 2;
+    const bool ssb_l = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_DIGI_L);
+    const bool ssb_u = (m == DDC_MODE_USB || m == DDC_MODE_CW_U || m == DDC_MODE_DIGI_U);
+    const bool hpf = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_USB || m == DDC_MODE_CW_U);
+    const bool fm = (m == DDC_MODE_NFM || m == DDC_MODE_WFM);
+    const bool chain = ssb_l || ssb_u || fm || m == DDC_MODE_AM;
+    const float *lk = ddc_lpf_k[s.lpf_idx], *lv = ddc_lpf_v[s.lpf_idx];
+    const float *hk = ddc_hpf_k[s.hpf_idx], *hv = ddc_hpf_v[s.hpf_idx];
+    const float vol = s.p.mute ? 0.0f : (float)s.p.volume / 100.0f;
+    float bi[kABlock], bq[kABlock];
+    for (uint32_t b0 = 0; b0 + kABlock <= n_frames; b0 += kABlock) {
+        for (int i = 0; i < kABlock; i++) {
+            const uint32_t v = src[b0 + i];
+            float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
+            if (s.p.iq_swap) { const float t = fi; fi = fq; fq = t; }
+            fi = dc_step(s, 0, fi) * s.p.rf_gain;
+            fq = dc_step(s, 1, fq) * s.p.rf_gain;
+            if (chain) {
+                if (hpf) { lattice_step(s.hpf_i, 6, hk, hv, fi); lattice_step(s.hpf_q, 6, hk, hv, fq); }
+                if (s.p.filter_width > 0) { lattice_step(s.lpf_i, s.lpf_n, lk, lv, fi); lattice_step(s.lpf_q, s.lpf_n, lk, lv, fq); }
+                if (ssb_l) fi = fi - fq;
+                else if (ssb_u) fi = fi + fq;
+                else if (m == DDC_MODE_AM) {
+                    const float p = fi * fi + fq * fq;
+                    fi = p >= 0.0f ? sqrtf(p) : 0.0f;
+                }
+            }
+            bi[i] = fi;
+            bq[i] = fq;
+        }
+        if (fm) fm_block(s, bi, bq);
+        if (chain && !fm && s.p.notch)
+            for (int i = 0; i < kABlock; i++) bi[i] = biquad_step(s.notch_c, s.notch_d, bi[i]);
+        for (int i = 0; i < kABlock; i++) {
+            if (bi[i] > s.smeter_max) s.smeter_max = bi[i];
+            if (bq[i] > s.smeter_max) s.smeter_max = bq[i];
+            if (bi[i] < s.smeter_min) s.smeter_min = bi[i];
+            if (bq[i] < s.smeter_min) s.smeter_min = bq[i];
+        }
+        if (chain) {
+            if (s.p.dnr)
+                for (int sb = 0; sb < kABlock / kASub; sb++) {
+                    float *x = bi + sb * kASub;
+                    for (int i = 0; i < kASub; i++) s.lms_ref[s.ref_new + i] = x[i];
+                    lms_block(s, x);
+                    s.ref_old += kASub;
+                    if (s.ref_old >= 128) s.ref_old = 0;
+                    s.ref_new = s.ref_old + kASub;
+                    if (s.ref_new >= 128) s.ref_new = 0;
+                }
+            agc_block(s, bi);
+            if (s.p.cw_decoder && (m == DDC_MODE_CW_L || m == DDC_MODE_CW_U)) cw_block(s, bi, 4ll * (int64_t)s.blocks);
+            for (int i = 0; i < kABlock; i++) bq[i] = bi[i];
+        }
+        for (int i = 0; i < kABlock; i++) {
+            dst[2 * (b0 + i)] = f2i_sat(bi[i] * vol);
+            dst[2 * (b0 + i) + 1] = f2i_sat(bq[i] * vol);
+        }
+        s.blocks++;
+    }
+    states[ch] = s;
+}
+
+/* ---- FFT panadapter ---------------------------------------------------------- */
+
+/* Pass A (thread = channel): DC filter and optional notch over the call's frames
+ * of 512 SPEC samples, in sequence; float I/Q to work: [channel][n][2]. */
+__global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__ states, uint32_t n_ch,
+                                                        const int16_t *__restrict__ spec_iq, uint32_t n,
+                                                        float2 *__restrict__ work)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_ch) return;
+    AudioState &s = states[ch];
+    float dx4 = s.dc_x[4], dy4 = s.dc_y[4], dx5 = s.dc_x[5], dy5 = s.dc_y[5];
+    float ni[2] = { s.notch_fi[0], s.notch_fi[1] }, nq[2] = { s.notch_fq[0], s.notch_fq[1] };
+    float c[5];
+    for (int i = 0; i < 5; i++) c[i] = s.notch_c[i];
+    const bool notch = s.p.notch, swap = s.p.iq_swap;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(spec_iq) + (size_t)ch * n;
+    float2 *dst = work + (size_t)ch * n;
+    const float A1 = 0.99951171875f;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t v = src[i];
+        float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
+        if (swap) { const float t = fi; fi = fq; fq = t; }
+        { const float d = fi - dx4; const float a = A1 * dy4; const float o = d + a; dx4 = fi; dy4 = o; fi = o; }
+        { const float d = fq - dx5; const float a = A1 * dy5; const float o = d + a; dx5 = fq; dy5 = o; fq = o; }
+        if (notch) { fi = biquad_step(c, ni, fi); fq = biquad_step(c, nq, fq); }
+        dst[i] = make_float2(fi, fq);
+    }
+    s.dc_x[4] = dx4; s.dc_y[4] = dy4; s.dc_x[5] = dx5; s.dc_y[5] = dy5;
+    s.notch_fi[0] = ni[0]; s.notch_fi[1] = ni[1]; s.notch_fq[0] = nq[0]; s.notch_fq[1] = nq[1];
+}
+
+__constant__ float c_fft_window[512]; // 0.54 - 0.46 cos(2 pi i / 511)
+__constant__ float2 c_fft_twiddle[256]; // exp(-2 pi i k / 512)
+
+/* Pass B (workgroup of 64 = one frame of one channel): Hamming window, 512-point
+ * radix-2 FFT in LDS, magnitude, 2:1 bin average, bin 0 := bin 1.
+ * mags: [channel][frames][256]. */
+__global__ __launch_bounds__(64) void ddc_fft_frames(const float2 *__restrict__ work, uint32_t frames_per_ch,
+                                                     float *__restrict__ mags)
+{
+    __shared__ float re[512], im[512];
+    const uint32_t fr = blockIdx.x, t = threadIdx.x;
+    const float2 *x = work + (size_t)fr * 512;
+    for (int j = 0; j < 8; j++) {
+        const int i = t + 64 * j;
+        const int r = (int)(__brev((unsigned)i) >> 23); // 9-bit reversal
+        const float2 v = x[i];
+        const float w = c_fft_window[i];
+        re[r] = w * v.x;
+        im[r] = w * v.y;
+    }
+    __syncthreads();
+    for (int len = 2, lg = 1; len <= 512; len <<= 1, lg++) {
+        const int half = len >> 1;
+        for (int j = 0; j < 4; j++) {
+            const int bf = t + 64 * j;           // butterfly 0..255
+            const int k = bf & (half - 1);
+            const int a = ((bf >> (lg - 1)) << lg) + k, b = a + half;
+            const float2 w = c_fft_twiddle[k << (9 - lg)];
+            const float xr = re[b] * w.x - im[b] * w.y, xi = re[b] * w.y + im[b] * w.x;
+            const float ar = re[a], ai = im[a];
+            re[b] = ar - xr; im[b] = ai - xi;
+            re[a] = ar + xr; im[a] = ai + xi;
+        }
+        __syncthreads();
+    }
+    float *out = mags + (size_t)fr * 256;
+    for (int j = 0; j < 4; j++) {
+        const int i = t + 64 * j;
+        const float m0 = sqrtf(re[2 * i] * re[2 * i] + im[2 * i] * im[2 * i]);
+        const float m1 = sqrtf(re[2 * i + 1] * re[2 * i + 1] + im[2 * i + 1] * im[2 * i + 1]);
+        out[i] = (m0 + m1) / 2;
+    }
+    __syncthreads();
+    if (t == 0) out[0] = out[1];
+    (void)frames_per_ch;
+}
+
+__device__ inline uint16_t fft_color(int height)
+{
+    int red = 0, green = 0, blue = 0;
+    const float c1 = 0.1f, c2 = 0.4f, c3 = 0.5f;
+    if (height < 30 * c1) blue = (int)(uint8_t)(int)(height * 255 / (30 * c1));
+    else if (height < 30 * (c1 + c2)) {
+        green = (int)(uint8_t)(int)((height - 30 * c1) * 255 / ((30 - 30 * c1) * (c1 + c2)));
+        red = green;
+        blue = (255 - green) & 255;
+    } else {
+        red = 255;
+        green = (int)(uint8_t)(int)(255 - (height - (30 * (c1 + c2))) * 255 / ((30 - (30 * (c1 + c2))) * (c1 + c2 + c3)));
+    }
+    return (uint16_t)(((red & 0xF8) << 8) | ((green & 0xFC) << 3) | (blue >> 3));
+}
+
+/* Pass C (workgroup of 256 = one channel, sequential over its frames): auto-level,
+ * normalise, temporal smoothing, then the waterfall row (fft-shifted RGB565) and
+ * the over-range count that feeds the next frame's auto-level. */
+__global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ states, const float *__restrict__ mags,
+                                                     uint32_t frames_per_ch, float *__restrict__ bins,
+                                                     uint16_t *__restrict__ rows)
+{
+    __shared__ float red[256];
+    __shared__ uint32_t errs;
+    __shared__ float s_max_value;
+    const uint32_t ch = blockIdx.x, x = threadIdx.x;
+    AudioState &s = states[ch];
+    float mean = s.fft_mean[x];
+    float max_value = s.fft_max_value;
+    uint32_t max_errors = s.fft_max_errors;
+    const float avg = (float)s.p.fft_averaging;
+    const bool loopback = s.p.mode == DDC_MODE_LOOPBACK;
+    for (uint32_t f = 0; f < frames_per_ch; f++) {
+        const size_t fr = (size_t)ch * frames_per_ch + f;
+        const float v = mags[fr * 256 + x];
+        red[x] = v;
+        if (x == 0) errs = 0;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)x < st) red[x] = fmaxf(red[x], red[x + st]);
+            __syncthreads();
+        }
+        if (x == 0) {
+            const float mx = red[0];
+            const float diff = (mx - max_value) / 10.0f;
+            const uint32_t e = max_errors;
+            float mv = max_value;
+            if (e >= 6 && diff > 0) mv += diff;
+            else if (e <= 1 && diff < 0 && diff < -10.0f) mv += diff;
+            else if (e <= 1 && mv > 10.0f) mv -= 10.0f;
+            else if (e <= 1 && diff < 0 && diff < -1.0f) mv += diff;
+            else if (e <= 1 && mv > 1.0f) mv -= 1.0f;
+            if (mv < 100.0f) mv = 100.0f;
+            if (loopback) mv = 60000;
+            s_max_value = mv;
+        }
+        __syncthreads();
+        max_value = s_max_value;
+        const float xn = v * (1.0f / max_value);
+        if (mean < xn) mean += (xn - mean) / avg;
+        else mean -= (mean - xn) / avg;
+        bins[fr * 256 + x] = mean;
+        const int nx = x < 128 ? x + 128 : x - 128;
+        int h = (int)(uint16_t)f2i_sat(mean * 30);
+        uint16_t c;
+        if (h > 29) { c = 0xF800; atomicAdd(&errs, 1u); }
+        else c = fft_color(h);
+        rows[fr * 256 + nx] = c;
+        __syncthreads();
+        max_errors = errs;
+        __syncthreads();
+    }
+    s.fft_mean[x] = mean;
+    if (x == 0) { s.fft_max_value = max_value; s.fft_max_errors = max_errors; }
+}
+
+} // namespace ddc
