@@ -128,6 +128,62 @@ void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_i
 /* Applies a command-1 payload to a channel: tuning word and RX/TX direction. */
 int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4]);
 
+/* ---- 48 kHz audio path and panadapter (the STM32 half of the reference) ------
+ *
+ * Demodulator modes, numbered as STM32/Src/trx_manager.h:11-22. */
+enum ddc_mode {
+    DDC_MODE_LSB = 0, DDC_MODE_USB, DDC_MODE_IQ, DDC_MODE_CW_L, DDC_MODE_CW_U, DDC_MODE_DIGI_L,
+    DDC_MODE_DIGI_U, DDC_MODE_NO_TX, DDC_MODE_NFM, DDC_MODE_WFM, DDC_MODE_AM, DDC_MODE_LOOPBACK
+};
+
+/* Per-channel operator settings: the fields of TRX / TRX.VFO the audio path reads
+ * (STM32/Src/settings.h:38-101).  filter_width is the LPF corner in Hz (0 = LPF
+ * off), hpf_pass the SSB high-pass corner (100..500, used in LSB/USB only),
+ * notch_fc the manual notch frequency, agc_speed 1..n, rf_gain the linear gain
+ * the firmware multiplies in (TRX.RF_Gain), volume 0..100, fft_averaging >= 1. */
+typedef struct ddc_audio_params {
+    uint8_t mode, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume;
+    uint8_t iq_swap, fft_averaging, pad0, pad1;
+    uint16_t filter_width, hpf_pass, notch_fc, agc_speed;
+    float rf_gain;
+} ddc_audio_params;
+
+typedef struct ddc_audio_status {
+    float smeter_max, smeter_min; /* Processor_RX_Audio_Samples_MAX/MIN_value, audio_processor.c:396-421 */
+    float agc_gain;               /* AGC_need_gain, agc.c */
+    float fft_max_value;          /* maxValueFFT, fft.c */
+    uint32_t cw_wpm;              /* CW_Decoder_WPM */
+    uint32_t squelched;           /* FM squelch state */
+    uint32_t blocks;              /* 192-frame blocks processed since configure */
+    char cw_text[16];             /* CW_Decoder_Text: last 15 decoded characters */
+} ddc_audio_status;
+
+/* initAudioProcessor + ReinitAudioFilters + InitNotchFilter + InitAGC +
+ * InitNoiseReduction + CWDecoder_Init for `channel` (-1 = all): filter selection
+ * (audio_filters.c:141-339), notch design (calcBiquad :375-494), state zeroed.
+ * Must be called before the first audio / FFT call.  -EINVAL when filter_width or
+ * hpf_pass name no table of the firmware. */
+int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p);
+/* processRxAudio (audio_processor.c:275-435) for all channels.  spec_iq/voice_iq:
+ * [n_channels][n_frames][2] int16 as ddc_rx_process_dev writes them; n_frames a
+ * multiple of 192 (the firmware's half-buffer); audio_lr: [n_channels][n_frames][2]
+ * int32, left then right, the codec buffer contents before the 16-bit word swap
+ * of the I2S DMA.  The _dev form takes device pointers and is asynchronous on the
+ * ctx stream. */
+int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames,
+                             int32_t *audio_lr);
+int ddc_audio_rx_process(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames,
+                         int32_t *audio_lr);
+/* FFT_doFFT (fft.c:212-331, zoom 1) + the colour row of FFT_printFFT (:361-379,
+ * :506-539) over consecutive 512-sample frames of SPEC.  n_frames a multiple of
+ * 512; bins: [n_channels][n_frames/512][256] float (FFTOutput_mean after each
+ * frame); rows: [n_channels][n_frames/512][256] RGB565 waterfall rows, already
+ * fft-shifted.  Either output may be NULL. */
+int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float *bins, uint16_t *rows);
+int ddc_fft_process(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float *bins, uint16_t *rows);
+/* S-meter extremes, AGC gain, CW decoder text (waits for the ctx stream). */
+int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
+
 /* Packed-ADC helpers and the synthetic test signal of the benchmark
  * (two tones + uniform noise, xorshift64* seeded 0x5EED0000 + channel). */
 void ddc_pack_adc12(const int16_t *samples, size_t n, uint8_t *packed);

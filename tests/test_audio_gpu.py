@@ -1,0 +1,172 @@
+"""Parity of the HIP 48 kHz audio path and FFT panadapter with the CPU oracle,
+through the C ABI.
+
+Tolerances.  Everything except the FM discriminator and the FFT is built from
+IEEE-754 single-precision add / multiply / divide / sqrt in the firmware's order
+with contraction off on both sides, so those modes are compared bit for bit.
+NFM / WFM go through atan2f, where the device math library and libm may differ
+by a few ulp: outputs must agree within 2e-4 of the block's full scale.  The FFT
+runs in float32 on the device and in float64 in the oracle: bins must agree
+within 1e-4 of the frame maximum; colours may differ only where a height sits on
+a rounding boundary."""
+import numpy as np
+import pytest
+
+from tests import audio_signals as sig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ddc():
+    import ua3reo_ddc
+    ua3reo_ddc.lib()
+    return ua3reo_ddc
+
+
+def make_inputs(n_ch, n, seed):
+    spec = np.stack([sig.noisy_two_tone(n, seed + 2 * c) for c in range(n_ch)])
+    voice = np.stack([sig.noisy_two_tone(n, seed + 2 * c + 1) for c in range(n_ch)])
+    return spec, voice
+
+
+def oracle_run(orc, params_per_ch, spec, voice):
+    out, st = [], []
+    for c, p in enumerate(params_per_ch):
+        a = orc.Audio(p)
+        out.append(a.rx(spec[c], voice[c]))
+        st.append(a.status())
+    return np.stack(out), st
+
+
+EXACT_CASES = [
+    dict(mode="USB"), dict(mode="LSB", hpf_pass=100, filter_width=3000),
+    dict(mode="USB", dnr=1), dict(mode="LSB", notch=1, notch_fc=1200),
+    dict(mode="CW_U", filter_width=500, cw_decoder=1), dict(mode="CW_L", filter_width=300),
+    dict(mode="DIGI_U", filter_width=3000), dict(mode="DIGI_L", filter_width=0),
+    dict(mode="AM", filter_width=6000), dict(mode="AM", filter_width=10000, dnr=1, notch=1),
+    dict(mode="IQ"), dict(mode="LOOPBACK"), dict(mode="USB", agc=0, iq_swap=1, volume=100),
+    dict(mode="USB", mute=1), dict(mode="USB", agc_speed=1, rf_gain=200.0, filter_width=15000),
+]
+
+
+def test_audio_modes_bit_exact(ddc, orc):
+    n = 192 * 40
+    n_ch = len(EXACT_CASES)
+    spec, voice = make_inputs(n_ch, n, 100)
+    d = ddc.Ddc(n_ch)
+    pg = [ddc.audio_params(**kw) for kw in EXACT_CASES]
+    po = [orc.audio_params(**kw) for kw in EXACT_CASES]
+    for c in range(n_ch):
+        d.audio_configure(pg[c], c)
+    got = d.audio_rx_process(spec, voice)
+    want, st = oracle_run(orc, po, spec, voice)
+    for c in range(n_ch):
+        assert np.array_equal(got[c], want[c]), "case %d %r: first diff at %s" % (
+            c, EXACT_CASES[c], np.argwhere(got[c] != want[c])[:3])
+        g = d.audio_status(c)
+        assert g["agc_gain"] == st[c]["agc_gain"]
+        assert g["smeter_max"] == st[c]["smeter_max"] and g["smeter_min"] == st[c]["smeter_min"]
+        assert g["blocks"] == 40
+    assert np.abs(got[0]).max() > 1000
+
+
+@pytest.mark.parametrize("sizes", [[192] * 6, [192 * 5, 192], [192 * 2, 192 * 3, 192]])
+def test_audio_streaming_calls_equal_one_call(ddc, orc, sizes):
+    total = sum(sizes)
+    spec, voice = make_inputs(3, total, 200)
+    cases = [dict(mode="USB", dnr=1, notch=1), dict(mode="AM"), dict(mode="CW_U", filter_width=500)]
+    d = ddc.Ddc(3)
+    for c, kw in enumerate(cases):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    outs, pos = [], 0
+    for s in sizes:
+        outs.append(d.audio_rx_process(spec[:, pos:pos + s], voice[:, pos:pos + s]))
+        pos += s
+    got = np.concatenate(outs, axis=1)
+    want, _ = oracle_run(orc, [orc.audio_params(**kw) for kw in cases], spec, voice)
+    assert np.array_equal(got, want)
+
+
+def test_audio_fm_within_tolerance(ddc, orc):
+    n = 192 * 60
+    cases = [dict(mode="NFM", filter_width=0), dict(mode="NFM", filter_width=10000, fm_sql_threshold=3),
+             dict(mode="WFM", filter_width=0), dict(mode="NFM", agc=0, volume=100, filter_width=0)]
+    spec = np.stack([sig.fm_iq(n, 500.0 + 300.0 * c, 2500.0, seed=c) for c in range(4)])
+    voice = np.zeros_like(spec)
+    d = ddc.Ddc(4)
+    for c, kw in enumerate(cases):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    got = d.audio_rx_process(spec, voice).astype(np.float64)
+    want, st = oracle_run(orc, [orc.audio_params(**kw) for kw in cases], spec, voice)
+    want = want.astype(np.float64)
+    for c in range(4):
+        scale = max(np.abs(want[c]).max(), 1.0)
+        assert np.abs(got[c] - want[c]).max() <= 2e-4 * scale + 1.0, "case %d" % c
+        assert d.audio_status(c)["squelched"] == st[c]["squelched"]
+    assert np.abs(want[0]).max() > 100
+
+
+def test_cw_decoder_text(ddc, orc):
+    voice = sig.cw_keyed("SOS SOS CQ DE TEST", wpm=20)[None]
+    kw = dict(mode="CW_U", agc=1, cw_decoder=1, rf_gain=10.0, volume=100, filter_width=500)
+    d = ddc.Ddc(1)
+    d.audio_configure(ddc.audio_params(**kw))
+    got = d.audio_rx_process(np.zeros_like(voice), voice)
+    a = orc.Audio(orc.audio_params(**kw))
+    want = a.rx(np.zeros_like(voice[0]), voice[0])
+    assert np.array_equal(got[0], want)
+    g, w = d.audio_status(0), a.status()
+    assert g["cw_text"] == w["cw_text"] and "CQ DE TEST" in g["cw_text"]
+    assert g["cw_wpm"] == w["cw_wpm"]
+
+
+def test_audio_saturation_and_errors(ddc, orc):
+    n = 192
+    spec = np.full((1, n, 2), 32767, np.int16)
+    spec[:, 1::2] = -32768
+    d = ddc.Ddc(1)
+    with pytest.raises(ddc.DdcError):
+        d.audio_rx_process(spec, spec)  # not configured yet
+    with pytest.raises(ddc.DdcError):
+        d.audio_configure(ddc.audio_params(filter_width=1234))
+    with pytest.raises(ddc.DdcError):
+        d.audio_configure(ddc.audio_params(mode="USB", hpf_pass=60))
+    d.audio_configure(ddc.audio_params(mode="IQ", rf_gain=1e6, volume=100))
+    out = d.audio_rx_process(spec, spec)
+    assert out.max() == 2 ** 31 - 1 and out.min() == -2 ** 31
+    with pytest.raises(ddc.DdcError):
+        d.audio_rx_process(spec[:, :100], spec[:, :100])  # not a multiple of 192
+
+
+def test_fft_frames_within_tolerance(ddc, orc):
+    n_ch, frames = 6, 24
+    n = 512 * frames
+    r = np.random.default_rng(7)
+    spec = np.stack([
+        sig.quantise(sig.tone_iq(n, 6000.0, 500.0) + r.normal(0, 5, (n, 2))),
+        sig.quantise(sig.tone_iq(n, -9000.0, 3000.0) + r.normal(0, 50, (n, 2))),
+        sig.quantise(r.normal(0, 3000.0, (n, 2))),
+        sig.noisy_two_tone(n, 41, amp=2000.0),
+        sig.quantise(np.concatenate([r.normal(0, 3000.0, (n // 2, 2)), np.zeros((n // 2, 2))])),
+        sig.noisy_two_tone(n, 43, amp=100.0),
+    ])
+    cases = [dict(fft_averaging=1), dict(fft_averaging=4), dict(fft_averaging=2), dict(fft_averaging=3, notch=1),
+             dict(fft_averaging=2), dict(fft_averaging=4, mode="LOOPBACK", iq_swap=1)]
+    d = ddc.Ddc(n_ch)
+    for c, kw in enumerate(cases):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    # two calls, to carry the auto-level and smoothing state across
+    b1, r1 = d.fft_process(spec[:, :512 * 10])
+    b2, r2 = d.fft_process(spec[:, 512 * 10:])
+    bins, rows = np.concatenate([b1, b2], axis=1), np.concatenate([r1, r2], axis=1)
+    mismatched_pixels = 0
+    for c in range(n_ch):
+        a = orc.Audio(orc.audio_params(**cases[c]))
+        for f in range(frames):
+            wb, wr, wh = a.fft(spec[c, 512 * f:512 * (f + 1)])
+            tol = 1e-4 * max(float(wb.max()), 1e-3)
+            assert np.abs(bins[c, f] - wb).max() <= tol, "channel %d frame %d" % (c, f)
+            mismatched_pixels += int((rows[c, f] != wr).sum())
+    assert mismatched_pixels <= 0.002 * n_ch * frames * 256
+    assert (rows[0, -1] >> 11).max() == 31  # something red on the carrier

@@ -527,13 +527,13 @@ __global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ st
         const float xn = v * (1.0f / max_value);
         if (mean < xn) mean += (xn - mean) / avg;
         else mean -= (mean - xn) / avg;
-        bins[fr * 256 + x] = mean;
+        if (bins) bins[fr * 256 + x] = mean;
         const int nx = x < 128 ? x + 128 : x - 128;
         int h = (int)(uint16_t)f2i_sat(mean * 30);
         uint16_t c;
         if (h > 29) { c = 0xF800; atomicAdd(&errs, 1u); }
         else c = fft_color(h);
-        rows[fr * 256 + nx] = c;
+        if (rows) rows[fr * 256 + nx] = c;
         __syncthreads();
         max_errors = errs;
         __syncthreads();

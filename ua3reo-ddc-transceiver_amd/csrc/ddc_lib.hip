@@ -14,6 +14,7 @@
 #include "../../include/ua3reo_ddc.h"
 #include "ddc_rx_kernels.hip.h"
 #include "ddc_tx_kernels.hip.h"
+#include "ddc_audio_kernels.hip.h"
 
 struct ddc_ctx {
     ddc_config cfg{};
@@ -42,6 +43,14 @@ struct ddc_ctx {
     size_t out_cap = 0;
     std::vector<uint32_t> h_phi;
     ddc_tx_state tx;
+    // 48 kHz audio path / panadapter: per-channel state and FFT work buffers
+    ddc::AudioState *d_audio = nullptr;
+    std::vector<uint8_t> audio_ready;  // per channel: ddc_audio_configure seen
+    float2 *d_fft_work = nullptr;      // [ch][n][2] prefiltered SPEC
+    float *d_fft_mag = nullptr;        // [ch][frames][256]
+    size_t fft_cap = 0;                // frames per channel the two hold
+    void *d_stage[3] = {nullptr, nullptr, nullptr}; // host-pointer entry points
+    size_t stage_cap[3] = {0, 0, 0};
     // optional per-call timing: HIP events on the ctx stream around the front
     // kernel and around the whole RX call
     bool profile = false;
@@ -202,6 +211,22 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     ctx->h_phi.assign(nch, 0);
+    ctx->audio_ready.assign(nch, 0);
+    CREATE_TRY(hipMalloc(&ctx->d_audio, nch * sizeof(ddc::AudioState)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_audio, 0, nch * sizeof(ddc::AudioState), ctx->stream));
+    {
+        // Hamming window as the firmware evaluates it (fft.c:249-251) and the
+        // 512-point twiddles
+        std::vector<float> win(512);
+        std::vector<float2> tw(256);
+        for (int i = 0; i < 512; i++) win[i] = 0.54f - 0.46f * cosf((2.0f * ddc::kPiF * i) / (512.0f - 1.0f));
+        for (int k = 0; k < 256; k++) {
+            const double a = -2.0 * 3.14159265358979323846 * k / 512.0;
+            tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_window), win.data(), 512 * sizeof(float)));
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_twiddle), tw.data(), 256 * sizeof(float2)));
+    }
     {
         int rc = ddc_tx_state_create(&ctx->tx, ctx->cfg.n_channels, ctx->stream);
         if (rc != 0) { ctx->err = "TX state allocation failed"; return bail(rc); }
@@ -219,7 +244,8 @@ void ddc_destroy(ddc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
-                     ctx->d_out };
+                     ctx->d_out, ctx->d_audio, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
+                     ctx->d_stage[2] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     ddc_tx_state_destroy(&ctx->tx);
@@ -549,6 +575,191 @@ int ddc_profile_collect(ddc_ctx *ctx, double *front_ms, double *tail_ms, uint32_
     *n_calls = (uint32_t)ctx->prof_count;
     ctx->prof_head = 0;
     ctx->prof_count = 0;
+    return 0;
+}
+
+/* ---- audio path and panadapter ---------------------------------------------- */
+
+int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (!p) return fail(ctx, -EINVAL, "null params");
+    if (p->mode > DDC_MODE_LOOPBACK) return fail(ctx, -EINVAL, "unknown mode");
+    if (p->agc_speed == 0 || p->fft_averaging == 0) return fail(ctx, -EINVAL, "agc_speed and fft_averaging must be >= 1");
+    ddc::AudioState st;
+    memset(&st, 0, sizeof st);
+    st.p = *p;
+    st.lpf_n = 7;
+    if (p->filter_width) {
+        int li = -1;
+        for (int i = 0; i < DDC_N_LPF; i++) if (ddc_lpf_hz[i] == p->filter_width) li = i;
+        if (li < 0) return fail(ctx, -EINVAL, "filter_width names no LPF table of the firmware");
+        st.lpf_idx = li;
+        st.lpf_n = ddc_lpf_stages[li];
+    }
+    if (p->mode == DDC_MODE_USB || p->mode == DDC_MODE_LSB) { // audio_filters.c:306-338
+        int hi = -1;
+        for (int i = 1; i < DDC_N_HPF; i++) if (ddc_hpf_hz[i] == p->hpf_pass) hi = i;
+        if (hi < 0) return fail(ctx, -EINVAL, "hpf_pass names no HPF table of the firmware");
+        st.hpf_idx = hi;
+    }
+    { // calcBiquad(BIQUAD_notch, fc, 48000, 0.5, 0), audio_filters.c:375-494
+        const uint32_t fs = 48000, fc = p->notch_fc;
+        const float q = 0.5f;
+        const float k = (float)tan(ddc::kPiF * fc / fs);
+        const float norm = (float)(1.0 / (1.0 + k / q + k * k));
+        const float a0 = (float)((1.0 + k * k) * norm);
+        const float a1 = (float)(2.0 * (k * k - 1.0) * norm);
+        const float b2 = (float)((1.0 - k / q + k * k) * norm);
+        st.notch_c[0] = a0; st.notch_c[1] = a1; st.notch_c[2] = a0; st.notch_c[3] = -a1; st.notch_c[4] = -b2;
+    }
+    st.agc_gain = 0.0f;
+    st.agc_gain_old = 1.0f;
+    st.agc_up = 500.0f / (float)p->agc_speed; // agc.c:9-19
+    st.agc_down = st.agc_up / 10.0f;
+    { // CWDecoder_Init, cw_decoder.c:41-54: bin k = (int)(0.5 + 192 * 350 / 48000) = 1
+        const float omega = (float)((2.0 * ddc::kPiF * 1) / 192);
+        st.cw_coeff = (float)(2.0 * cosf(omega));
+        st.cw_limit = 50;
+        st.cw_limit_low = 50;
+        memset(st.cw_text, ' ', 15);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t lo = channel < 0 ? 0 : (size_t)channel;
+    const size_t hi = channel < 0 ? ctx->cfg.n_channels : lo + 1;
+    std::vector<ddc::AudioState> all(hi - lo, st);
+    HIP_TRY(ctx, hipMemcpy(ctx->d_audio + lo, all.data(), all.size() * sizeof st, hipMemcpyHostToDevice));
+    for (size_t c = lo; c < hi; c++) ctx->audio_ready[c] = 1;
+    return 0;
+}
+
+static int audio_all_ready(ddc_ctx *ctx)
+{
+    for (uint8_t r : ctx->audio_ready)
+        if (!r) return fail(ctx, -EINVAL, "ddc_audio_configure has not been called for every channel");
+    return 0;
+}
+
+int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames,
+                             int32_t *audio_lr)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!spec_iq || !voice_iq || !audio_lr) return fail(ctx, -EINVAL, "null buffer");
+    if (n_frames % ddc::kABlock) return fail(ctx, -EINVAL, "n_frames must be a multiple of 192");
+    if (n_frames > 0xFFFFFF00u) return fail(ctx, -EINVAL, "n_frames too large");
+    int rc = audio_all_ready(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const uint32_t nch = ctx->cfg.n_channels;
+    hipLaunchKernelGGL(ddc::ddc_audio_rx, dim3((nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, nch, spec_iq,
+                       voice_iq, (uint32_t)n_frames, audio_lr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+static int ensure_stage(ddc_ctx *ctx, int slot, size_t bytes)
+{
+    if (bytes <= ctx->stage_cap[slot]) return 0;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage[slot]) (void)hipFree(ctx->d_stage[slot]);
+    ctx->d_stage[slot] = nullptr;
+    ctx->stage_cap[slot] = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_stage[slot], bytes));
+    ctx->stage_cap[slot] = bytes;
+    return 0;
+}
+
+int ddc_audio_rx_process(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames,
+                         int32_t *audio_lr)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!spec_iq || !voice_iq || !audio_lr) return fail(ctx, -EINVAL, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t in_b = (size_t)ctx->cfg.n_channels * n_frames * 4, out_b = in_b * 2;
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, in_b)) || (rc = ensure_stage(ctx, 1, in_b)) || (rc = ensure_stage(ctx, 2, out_b))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], spec_iq, in_b, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[1], voice_iq, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = ddc_audio_rx_process_dev(ctx, (const int16_t *)ctx->d_stage[0], (const int16_t *)ctx->d_stage[1], n_frames,
+                                  (int32_t *)ctx->d_stage[2]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(audio_lr, ctx->d_stage[2], out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float *bins, uint16_t *rows)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!spec_iq) return fail(ctx, -EINVAL, "null buffer");
+    if (n_frames % 512) return fail(ctx, -EINVAL, "n_frames must be a multiple of 512");
+    const size_t fpc = n_frames / 512;
+    const size_t nch = ctx->cfg.n_channels;
+    if (nch * fpc > 0x7FFFFFFFu) return fail(ctx, -EINVAL, "too many FFT frames in one call");
+    int rc = audio_all_ready(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    if (fpc > ctx->fft_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_fft_work) (void)hipFree(ctx->d_fft_work);
+        if (ctx->d_fft_mag) (void)hipFree(ctx->d_fft_mag);
+        ctx->d_fft_work = nullptr; ctx->d_fft_mag = nullptr; ctx->fft_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_fft_work, nch * fpc * 512 * sizeof(float2)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_fft_mag, nch * fpc * 256 * sizeof(float)));
+        ctx->fft_cap = fpc;
+    }
+    hipLaunchKernelGGL(ddc::ddc_fft_prefilter, dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, ctx->stream, ctx->d_audio,
+                       (uint32_t)nch, spec_iq, (uint32_t)n_frames, ctx->d_fft_work);
+    hipLaunchKernelGGL(ddc::ddc_fft_frames, dim3((unsigned)(nch * fpc)), dim3(64), 0, ctx->stream, ctx->d_fft_work,
+                       (uint32_t)fpc, ctx->d_fft_mag);
+    hipLaunchKernelGGL(ddc::ddc_fft_level, dim3((unsigned)nch), dim3(256), 0, ctx->stream, ctx->d_audio, ctx->d_fft_mag,
+                       (uint32_t)fpc, bins, rows);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ddc_fft_process(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float *bins, uint16_t *rows)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!spec_iq) return fail(ctx, -EINVAL, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t nch = ctx->cfg.n_channels;
+    const size_t in_b = nch * n_frames * 4, nb = nch * (n_frames / 512) * 256;
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, in_b)) || (rc = ensure_stage(ctx, 1, nb * 4)) || (rc = ensure_stage(ctx, 2, nb * 2))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], spec_iq, in_b, hipMemcpyHostToDevice, ctx->stream));
+    rc = ddc_fft_process_dev(ctx, (const int16_t *)ctx->d_stage[0], n_frames, (float *)ctx->d_stage[1],
+                             (uint16_t *)ctx->d_stage[2]);
+    if (rc) return rc;
+    if (bins) HIP_TRY(ctx, hipMemcpyAsync(bins, ctx->d_stage[1], nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (rows) HIP_TRY(ctx, hipMemcpyAsync(rows, ctx->d_stage[2], nb * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0 || !out) return fail(ctx, -EINVAL, "ddc_audio_get_status needs one channel and an output");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    static thread_local ddc::AudioState st;
+    HIP_TRY(ctx, hipMemcpy(&st, ctx->d_audio + channel, sizeof st, hipMemcpyDeviceToHost));
+    out->smeter_max = st.smeter_max;
+    out->smeter_min = st.smeter_min;
+    out->agc_gain = st.agc_gain;
+    out->fft_max_value = st.fft_max_value;
+    out->cw_wpm = st.cw_wpm;
+    out->squelched = st.squelched;
+    out->blocks = st.blocks;
+    memcpy(out->cw_text, st.cw_text, 16);
     return 0;
 }
 

@@ -95,6 +95,12 @@ def lib():
     L.ddc_pack_adc12.restype = None
     L.ddc_unpack_adc12.argtypes = [vp, sz, vp]
     L.ddc_unpack_adc12.restype = None
+    L.ddc_audio_configure.argtypes = [vp, i32, vp]
+    L.ddc_audio_rx_process_dev.argtypes = [vp, vp, vp, sz, vp]
+    L.ddc_audio_rx_process.argtypes = [vp, vp, vp, sz, vp]
+    L.ddc_fft_process_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.ddc_fft_process.argtypes = [vp, vp, sz, vp, vp]
+    L.ddc_audio_get_status.argtypes = [vp, i32, vp]
     L.ddc_synth_adc.argtypes = [u32, u32, sz, vp]
     L.ddc_synth_adc.restype = None
     _lib = L
@@ -104,6 +110,36 @@ def lib():
 class _Config(C.Structure):
     _fields_ = [("n_channels", C.c_uint32), ("fs_adc", C.c_uint32), ("device", C.c_int32),
                 ("reserved", C.c_uint32)]
+
+
+MODES = {"LSB": 0, "USB": 1, "IQ": 2, "CW_L": 3, "CW_U": 4, "DIGI_L": 5, "DIGI_U": 6, "NO_TX": 7,
+         "NFM": 8, "WFM": 9, "AM": 10, "LOOPBACK": 11}
+
+
+class AudioParams(C.Structure):
+    """ddc_audio_params: the TRX / VFO settings the audio path reads
+    (STM32/Src/settings.h:38-101)."""
+    _fields_ = [("mode", C.c_uint8), ("agc", C.c_uint8), ("dnr", C.c_uint8), ("notch", C.c_uint8),
+                ("mute", C.c_uint8), ("cw_decoder", C.c_uint8), ("fm_sql_threshold", C.c_uint8),
+                ("volume", C.c_uint8), ("iq_swap", C.c_uint8), ("fft_averaging", C.c_uint8),
+                ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("filter_width", C.c_uint16),
+                ("hpf_pass", C.c_uint16), ("notch_fc", C.c_uint16), ("agc_speed", C.c_uint16),
+                ("rf_gain", C.c_float)]
+
+
+class AudioStatus(C.Structure):
+    _fields_ = [("smeter_max", C.c_float), ("smeter_min", C.c_float), ("agc_gain", C.c_float),
+                ("fft_max_value", C.c_float), ("cw_wpm", C.c_uint32), ("squelched", C.c_uint32),
+                ("blocks", C.c_uint32), ("cw_text", C.c_char * 16)]
+
+
+def audio_params(mode="USB", agc=1, dnr=0, notch=0, mute=0, cw_decoder=0, fm_sql_threshold=0, volume=50,
+                 iq_swap=0, fft_averaging=4, filter_width=2700, hpf_pass=300, notch_fc=1000, agc_speed=3,
+                 rf_gain=50.0):
+    """Defaults follow LoadSettings (STM32/Src/settings.c:33-120) where it names one."""
+    m = MODES[mode] if isinstance(mode, str) else int(mode)
+    return AudioParams(m, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume, iq_swap, fft_averaging,
+                       0, 0, filter_width, hpf_pass, notch_fc, agc_speed, rf_gain)
 
 
 def _np_ptr(a):
@@ -202,6 +238,42 @@ class Ddc:
 
     def tx_set_phase(self, channel, phase):
         self._check(self._L.ddc_tx_set_phase(self._h, channel, int(phase)))
+
+    def audio_configure(self, params, channel=-1):
+        self._check(self._L.ddc_audio_configure(self._h, channel, C.byref(params)))
+
+    def audio_rx_process(self, spec_iq, voice_iq):
+        """Host path. spec/voice int16 [n_channels][n][2] -> int32 [n_channels][n][2] (L, R)."""
+        s = np.ascontiguousarray(spec_iq, dtype=np.int16)
+        v = np.ascontiguousarray(voice_iq, dtype=np.int16)
+        assert s.shape == v.shape and s.ndim == 3 and s.shape[0] == self.n_channels and s.shape[2] == 2
+        out = np.zeros(s.shape, np.int32)
+        self._check(self._L.ddc_audio_rx_process(self._h, _np_ptr(s), _np_ptr(v), s.shape[1], _np_ptr(out)))
+        return out
+
+    def audio_rx_process_dev(self, spec_ptr, voice_ptr, n_frames, audio_ptr):
+        self._check(self._L.ddc_audio_rx_process_dev(self._h, spec_ptr, voice_ptr, n_frames, audio_ptr))
+
+    def fft_process(self, spec_iq):
+        """Host path. spec int16 [n_channels][n][2], n % 512 == 0 -> (bins float32
+        [n_channels][n/512][256], rows uint16 [n_channels][n/512][256])."""
+        s = np.ascontiguousarray(spec_iq, dtype=np.int16)
+        assert s.ndim == 3 and s.shape[0] == self.n_channels and s.shape[2] == 2
+        nf = s.shape[1] // 512
+        bins = np.zeros((self.n_channels, nf, 256), np.float32)
+        rows = np.zeros((self.n_channels, nf, 256), np.uint16)
+        self._check(self._L.ddc_fft_process(self._h, _np_ptr(s), s.shape[1], _np_ptr(bins), _np_ptr(rows)))
+        return bins, rows
+
+    def fft_process_dev(self, spec_ptr, n_frames, bins_ptr, rows_ptr):
+        self._check(self._L.ddc_fft_process_dev(self._h, spec_ptr, n_frames, bins_ptr, rows_ptr))
+
+    def audio_status(self, channel):
+        st = AudioStatus()
+        self._check(self._L.ddc_audio_get_status(self._h, channel, C.byref(st)))
+        return {"smeter_max": st.smeter_max, "smeter_min": st.smeter_min, "agc_gain": st.agc_gain,
+                "fft_max_value": st.fft_max_value, "cw_wpm": st.cw_wpm, "squelched": bool(st.squelched),
+                "blocks": st.blocks, "cw_text": bytes(st.cw_text).split(b"\0")[0].decode("ascii", "replace")}
 
     def sync(self):
         self._check(self._L.ddc_sync(self._h))
