@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "ua3reo-ddc-transceiver_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+METRIC = "ADC MSamples/s ingested per node, N-channel DDC; % HBM roofline"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 BYTES_PER_CHANNEL_SAMPLE = 1.5 + 8.0 / 1024.0  # packed ADC read + SPEC/VOICE int16 I/Q written
 FS_ADC = 49152000
@@ -60,6 +61,20 @@ def synth_rows(n_channels, samples, chan0, device, seed):
         blk[:, :, 2] = (s1 >> 4).to(torch.uint8)
         del x, s0, s1
     return out
+
+
+def measured_traffic(nch, samples):
+    """HBM-side bytes per ddc_rx_front launch from the last committed PMC passes
+    (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE), if they were taken on
+    this workload shape; rocprofv3 counters cannot be read from inside the run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t["channels"] == nch and t["samples"] == samples:
+            return float(t["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(n_threads, samples=1 << 22, distinct=4, reps=6):
@@ -95,6 +110,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--samples", type=int, default=1 << 20, help="ADC samples per channel per step")
+    ap.add_argument("--workload", choices=["ddc", "ddc+fft", "tx"], default="ddc",
+                    help="ddc: RX chain (the headline metric); ddc+fft: RX chain + one 512-point panadapter "
+                         "row per 512 SPEC samples (config 3 shape: --channels 256 --samples 4194304); "
+                         "tx: DUC, --samples = DAC samples per channel (config 4 shape: --channels 256 "
+                         "--samples 4194304)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
@@ -113,25 +133,51 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import ua3reo_ddc
+    if args.workload == "tx":
+        return bench_tx(args, dev, local_rank, rank, world, dist)
     nch, S = args.channels, args.samples
     assert S % 1024 == 0
     nf = S // 1024
     rb = S // 2 * 3
     chan0 = rank * nch
     adc = synth_rows(nch, S, chan0, dev, 0x5EED0000 + rank)
-    out = torch.zeros((2, nch, nf, 2), dtype=torch.int16, device=dev)  # [SPEC|VOICE]
-    gathered = torch.zeros((world,) + tuple(out.shape), dtype=torch.int16, device=dev) if world > 1 else None
+    # [buffer][SPEC|VOICE][channel][frame][I,Q]; two buffers so that the gather of
+    # step k overlaps the compute of step k+1
+    outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
+    out = outs[0]
+    gathered = torch.zeros((world * 2, nch, nf, 2), dtype=torch.int16, device=dev) if world > 1 else None
+    with_fft = args.workload == "ddc+fft"
+    if with_fft:
+        assert nf % 512 == 0, "ddc+fft needs samples to be a multiple of 512*1024"
+        fft_bins = torch.zeros((nch, nf // 512, 256), dtype=torch.float32, device=dev)
+        fft_rows = torch.zeros((nch, nf // 512, 256), dtype=torch.int16, device=dev)
     phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * (chan0 + c))[0] for c in range(nch)]
     ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
     ctx.tune_many(phis)
+    if with_fft:
+        ctx.audio_configure(ua3reo_ddc.audio_params(mode="USB", fft_averaging=4))
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    computed = [torch.cuda.Event(), torch.cuda.Event()]
+    gathered_ev = [torch.cuda.Event(), torch.cuda.Event()]
+    step_no = [0]
     torch.cuda.synchronize()
 
     def step():
-        ctx.rx_process_dev(adc.data_ptr(), rb, S, out[0].data_ptr(), out[1].data_ptr())
+        b = step_no[0] & 1
+        step_no[0] += 1
+        o = outs[b]
+        if world > 1 and step_no[0] > 2:
+            ext.wait_event(gathered_ev[b])  # the gather that last read this buffer
+        ctx.rx_process_dev(adc.data_ptr(), rb, S, o[0].data_ptr(), o[1].data_ptr())
+        if with_fft:
+            ctx.fft_process_dev(o[0].data_ptr(), nf, fft_bins.data_ptr(), fft_rows.data_ptr())
         if world > 1:
-            with torch.cuda.stream(ext):
-                dist.all_gather_into_tensor(gathered, out)
+            computed[b].record(ext)
+            comm.wait_event(computed[b])
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(gathered.view(torch.uint8), o.view(torch.uint8))
+                gathered_ev[b].record(comm)
 
     # parity spot check before any timing: first step from power-on state vs the oracle
     check = "skipped"
@@ -184,7 +230,7 @@ def main():
         front_avg_ms = front_ms / max(1, ncalls)
         achieved = BYTES_PER_CHANNEL_SAMPLE * nch * S / (front_avg_ms * 1e-3) / 1e9
         res = {
-            "metric": "ADC MSamples/s ingested per node, N-channel DDC",
+            "metric": METRIC,
             "value": round(value, 1),
             "unit": "MS/s",
             "n_gpus": world,
@@ -197,14 +243,16 @@ def main():
             "dtype": "i32/i64 integer (12-bit ADC, 60-bit CIC)",
             "data": "synthetic: two tones + uniform noise per channel, packed 12-bit, generated on device",
             "config": {
-                "workload": "per-GPU shard of BASELINE config 5: %d channels x %d ADC samples per step, "
-                            "full FPGA RX chain (NCO+mixer+rx_cic+rx_ciccomp+rx_hilb/delay) to SPEC+VOICE int16 I/Q"
-                            % (nch, S),
+                "workload": "%s: %d channels x %d ADC samples per step, "
+                            "full FPGA RX chain (NCO+mixer+rx_cic+rx_ciccomp+rx_hilb/delay) to SPEC+VOICE int16 I/Q%s"
+                            % ("per-GPU shard of BASELINE config 5" if not with_fft else "BASELINE config 3 shape",
+                               nch, S, " + 512-point FFT panadapter rows" if with_fft else ""),
                 "channels_per_gpu": nch,
                 "samples_per_channel": S,
                 "fs_adc_hz": FS_ADC,
                 "parallelism": "channels sharded over %d GPU(s)%s" % (
-                    world, ", RCCL all-gather of decimated I/Q each step" if world > 1 else ""),
+                    world, ", RCCL all-gather of decimated I/Q each step, overlapped with the next step"
+                    if world > 1 else ""),
                 "parity_check": check,
             },
             "roofline": {
@@ -214,7 +262,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(nch, S),
                 "avg_launch_ms": round(front_avg_ms, 4),
                 "rest_of_call_ms": round(tail_ms / max(1, ncalls), 4),
                 "algorithmic_bytes_per_launch": BYTES_PER_CHANNEL_SAMPLE * nch * S,
@@ -225,6 +273,87 @@ def main():
             v, sample = cpu_baseline(threads)
             res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": threads,
                                    "kind": "port", "sample": sample}
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_tx(args, dev, local_rank, rank, world, dist):
+    """DUC: 48 kHz I/Q -> tx_ciccomp x2 -> tx_cic x512 -> mixer -> 14-bit DAC words.
+    One step = args.samples DAC samples per channel; HBM traffic is the 2-byte DAC
+    word written per sample plus 4 bytes read per 1024."""
+    import ua3reo_ddc
+    nch, S = args.channels, args.samples
+    assert S % 1024 == 0
+    n_iq = S // 1024
+    g = torch.Generator(device=dev).manual_seed(0x7E57 + rank)
+    iq = torch.randint(-20000, 20000, (nch, n_iq, 2), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    dac = torch.zeros((nch, S), dtype=torch.int16, device=dev)
+    chan0 = rank * nch
+    phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * (chan0 + c))[0] for c in range(nch)]
+    ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
+    ctx.tune_many(phis)
+    check = "skipped"
+    if not args.no_check:
+        from oracle import oracle
+        k = min(n_iq, 8)
+        # contiguous-row form: run k pairs of every channel from a compact copy
+        iq_k = iq[:, :k].contiguous()
+        dac_k = torch.zeros((nch, k * 1024), dtype=torch.int16, device=dev)
+        chk = ua3reo_ddc.Ddc(nch, device=local_rank)
+        chk.tune_many(phis)
+        chk.tx_process_dev(iq_k.data_ptr(), k, dac_k.data_ptr())
+        chk.sync()
+        for c in sorted({0, nch // 2, nch - 1}):
+            want = oracle.TxChain(phis[c]).run(iq_k[c].cpu().numpy())
+            if not np.array_equal(dac_k[c].cpu().numpy().view(np.uint16), want):
+                raise SystemExit("bench: GPU DAC stream differs from the oracle on channel %d" % c)
+        chk.close()
+        check = "bit-exact vs oracle on 3 channels x %d DAC samples" % (k * 1024)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    for _ in range(args.warmup):
+        ctx.tx_process_dev(iq.data_ptr(), n_iq, dac.data_ptr())
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ev0.record(ext)
+    for _ in range(args.steps):
+        ctx.tx_process_dev(iq.data_ptr(), n_iq, dac.data_ptr())
+    ev1.record(ext)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    call_ms = ev0.elapsed_time(ev1) / args.steps
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        bytes_per = 2.0 + 4.0 / 1024.0
+        achieved = bytes_per * nch * S / (call_ms * 1e-3) / 1e9
+        res = {
+            "metric": "DAC MSamples/s produced per node, N-channel DUC",
+            "value": round(float(world) * nch * S * args.steps / dt / 1e6, 1), "unit": "MS/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i32/i64 integer (16-bit I/Q, 60-bit CIC, 14-bit DAC)",
+            "data": "synthetic: uniform random 48 kHz I/Q, generated on device",
+            "config": {"workload": "BASELINE config 4 shape: %d channels x %d I/Q pairs -> %d DAC words per channel "
+                                   "per step (tx_ciccomp + tx_cic + tx_mixer + DAC_corrector)" % (nch, n_iq, S),
+                       "channels_per_gpu": nch, "parity_check": check},
+            "roofline": {"bound": "hbm", "kernel": "whole ddc_tx_process_dev call (ddc_tx_duc dominates)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_ms": round(call_ms, 4)},
+        }
         print(json.dumps(res), flush=True)
     ctx.close()
     if dist is not None:

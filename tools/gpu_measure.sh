@@ -1,0 +1,39 @@
+#!/bin/bash
+# usage: tools/gpu_measure.sh <tag>
+# One measurement round on the GPU box: default bench line, kernel-trace stats of
+# the same command, two PMC passes (HBM read / write bytes), and the config-3 and
+# config-4 shaped workloads.  Every GPU step has its own time limit; the script
+# stops at the first failure.
+set -o pipefail
+tag=${1:-run}
+export TMPDIR=/tmp
+out=gpurun_out/$tag
+mkdir -p $out
+step() { echo "== $*"; }
+
+step bench
+timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -20 $out/bench.err; exit 1; }
+cat $out/bench.json
+
+step kernel-trace
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --no-cpu-baseline > $out/trace.log 2>&1 || { echo "trace failed"; tail -20 $out/trace.log; exit 1; }
+find $out/trace -name "*kernel_stats.csv" | head -1 | xargs -r cat > $out/kernel_stats.csv
+head -20 $out/kernel_stats.csv
+
+step pmc-fetch
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check > $out/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -20 $out/pmc_fetch.log; exit 1; }
+step pmc-write
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check > $out/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -20 $out/pmc_write.log; exit 1; }
+python3 tools/pmc_summary.py $out/pmc_fetch > $out/pmc_summary.txt
+python3 tools/pmc_summary.py $out/pmc_write >> $out/pmc_summary.txt
+cat $out/pmc_summary.txt
+# keep only the summaries (the raw csv files are large)
+rm -rf $out/pmc_fetch $out/pmc_write $out/trace
+
+step config-3-shape
+timeout -k 10 300 python3 bench.py --workload ddc+fft --channels 256 --samples 4194304 --steps 10 --no-cpu-baseline > $out/bench_cfg3.json 2> $out/bench_cfg3.err || { echo "cfg3 failed"; tail -20 $out/bench_cfg3.err; exit 1; }
+cat $out/bench_cfg3.json
+step config-4-shape
+timeout -k 10 300 python3 bench.py --workload tx --channels 256 --samples 4194304 --steps 10 > $out/bench_cfg4.json 2> $out/bench_cfg4.err || { echo "cfg4 failed"; tail -20 $out/bench_cfg4.err; exit 1; }
+cat $out/bench_cfg4.json
+echo "== done"
