@@ -140,10 +140,14 @@ enum ddc_mode {
  * (STM32/Src/settings.h:38-101).  filter_width is the LPF corner in Hz (0 = LPF
  * off), hpf_pass the SSB high-pass corner (100..500, used in LSB/USB only),
  * notch_fc the manual notch frequency, agc_speed 1..n, rf_gain the linear gain
- * the firmware multiplies in (TRX.RF_Gain), volume 0..100, fft_averaging >= 1. */
+ * the firmware multiplies in (TRX.RF_Gain), volume 0..100, fft_averaging >= 1,
+ * fft_zoom 1 (off), 2, 4, 8 or 16 (TRX.FFT_Zoom), rf_power 0..100 (TRX.RF_Power),
+ * tune = TRX_tune, key = CW key / PTT down (TRX_key_serial | TRX_ptt_hard |
+ * TRX_key_hard). */
 typedef struct ddc_audio_params {
     uint8_t mode, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume;
-    uint8_t iq_swap, fft_averaging, pad0, pad1;
+    uint8_t iq_swap, fft_averaging, fft_zoom, rf_power;
+    uint8_t tune, key, pad0, pad1;
     uint16_t filter_width, hpf_pass, notch_fc, agc_speed;
     float rf_gain;
 } ddc_audio_params;
@@ -154,7 +158,9 @@ typedef struct ddc_audio_status {
     float fft_max_value;          /* maxValueFFT, fft.c */
     uint32_t cw_wpm;              /* CW_Decoder_WPM */
     uint32_t squelched;           /* FM squelch state */
-    uint32_t blocks;              /* 192-frame blocks processed since configure */
+    uint32_t blocks;              /* 192-frame RX blocks processed since configure */
+    float alc_gain;               /* ALC_need_gain, audio_processor.c:34 */
+    float tx_max_amplitude;       /* Processor_TX_MAX_amplitude */
     char cw_text[16];             /* CW_Decoder_Text: last 15 decoded characters */
 } ddc_audio_status;
 
@@ -178,10 +184,23 @@ int ddc_audio_rx_process(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *vo
  * :506-539) over consecutive 512-sample frames of SPEC.  n_frames a multiple of
  * 512; bins: [n_channels][n_frames/512][256] float (FFTOutput_mean after each
  * frame); rows: [n_channels][n_frames/512][256] RGB565 waterfall rows, already
- * fft-shifted.  Either output may be NULL. */
+ * fft-shifted.  Either output may be NULL.  With fft_zoom = M > 1 every frame is
+ * low-passed, decimated by M and slid into the last 512 decimated samples first
+ * (fft.c:236-261), so one row still comes out per 512 input samples. */
 int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float *bins, uint16_t *rows);
 int ddc_fft_process(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float *bins, uint16_t *rows);
-/* S-meter extremes, AGC gain, CW decoder text (waits for the ctx stream). */
+/* processTxAudio (audio_processor.c:61-273) + ModulateFM (:590-619) for all
+ * channels.  mic_lr: [n_channels][n_frames][2] int16, the codec / USB-audio
+ * capture (left, right); n_frames a multiple of 192; iq48k: [n_channels][n_frames][2]
+ * int16 (I, Q) as FPGA_fpgadata_sendiq narrows them for the bus (fpga.c:403-436),
+ * ready for ddc_tx_process; loop_lr: [n_channels][n_frames][2] int32, the codec
+ * output of LOOPBACK mode (zero in other modes; iq48k is zero in LOOPBACK), may
+ * be NULL.  Shares the HPF / LPF lattice state and DC-blocker slots with nothing
+ * on the RX side except the filter instances the firmware itself shares
+ * (IIR_HPF_I, IIR_LPF_I). */
+int ddc_audio_tx_process_dev(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, int16_t *iq48k, int32_t *loop_lr);
+int ddc_audio_tx_process(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, int16_t *iq48k, int32_t *loop_lr);
+/* S-meter extremes, AGC / ALC gain, CW decoder text (waits for the ctx stream). */
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
 
 /* Packed-ADC helpers and the synthetic test signal of the benchmark

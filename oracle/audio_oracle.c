@@ -31,7 +31,8 @@ enum { MODE_LSB, MODE_USB, MODE_IQ, MODE_CW_L, MODE_CW_U, MODE_DIGI_L, MODE_DIGI
 
 typedef struct {
     uint8_t mode, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume;
-    uint8_t iq_swap, fft_averaging, pad0, pad1;
+    uint8_t iq_swap, fft_averaging, fft_zoom, rf_power;
+    uint8_t tune, key, pad0, pad1;
     uint16_t filter_width, hpf_pass, notch_fc, agc_speed;
     float rf_gain;
 } orc_audio_params_t;
@@ -132,6 +133,17 @@ typedef struct {
     /* FFT, fft.c */
     float fft_mean[FFT_PRINT], fft_max_value;
     uint16_t fft_max_errors;
+    /* zoom FFT (fft.c:44-209,236-261): 4-stage DF1 biquad, 4-tap decimator, sliding buffer */
+    float zoom_c[20], zoom_fir[4];
+    float zoom_bq_i[16], zoom_bq_q[16];       /* per stage x1,x2,y1,y2 */
+    float zoom_dec_i[3], zoom_dec_q[3];       /* the numTaps-1 samples before the block */
+    float zoom_buf[2 * FFT_SIZE];             /* FFTInput_ZOOMFFT, interleaved */
+    /* TX (audio_processor.c:61-273,590-619) */
+    float tx_fir_i[200], tx_fir_q[200];       /* Fir_Tx_Hilbert_State_I/Q: the 200 samples before the block */
+    float alc_gain;                           /* ALC_need_gain */
+    float txfm_hpf_a, txfm_hpf_b, txfm_index;
+    uint32_t txfm_accum;
+    float tx_max_amplitude;
 } orc_audio_t;
 
 size_t orc_audio_sizeof(void) { return sizeof(orc_audio_t); }
@@ -157,6 +169,31 @@ static void notch_coeffs(uint32_t fc, float c[5])
     const float b2 = (float)((1.0 - k / q + k * k) * norm);
     c[0] = a0; c[1] = a1; c[2] = a2; c[3] = -b1; c[4] = -b2;
 }
+
+/* Zoom-FFT coefficient sets, fft.c:76-186 (literals are double in the firmware and
+ * narrow to float32 when stored) */
+static const double zoom_biquad[4][20] = {
+    { 0.228454526413293696,0.077639329099949764,0.228454526413293696,0.635534925142242080,-0.170083307068779194,
+      0.436788292542003964,0.232307972937606161,0.436788292542003964,0.365885230717786780,-0.471769788739400842,
+      0.535974654742658707,0.557035600464780845,0.535974654742658707,0.125740787233286133,-0.754725697183384336,
+      0.501116342273565607,0.914877831284765408,0.501116342273565607,0.013862536615004284,-0.930973052446900984 },
+    { 0.182208761527446556,-0.222492493114674145,0.182208761527446556,1.326111070880959810,-0.468036100821178802,
+      0.337123762652097259,-0.366352718812586853,0.337123762652097259,1.337053579516321200,-0.644948386007929031,
+      0.336163175380826074,-0.199246162162897811,0.336163175380826074,1.354952684569386670,-0.828032873168141115,
+      0.178588201750411041,0.207271695028067304,0.178588201750411041,1.386486967455699220,-0.950935065984588657 },
+    { 0.185643392652478922,-0.332064345389014803,0.185643392652478922,1.654637402827731090,-0.693859842743674182,
+      0.327519300813245984,-0.571358085216950418,0.327519300813245984,1.715375037176782860,-0.799055553586324407,
+      0.283656142708241688,-0.441088976843048652,0.283656142708241688,1.778230635987093860,-0.904453944560528522,
+      0.079685368654848945,-0.011231810140649204,0.079685368654848945,1.825046003243238070,-0.973184930412286708 },
+    { 0.194769868656866380,-0.379098413160710079,0.194769868656866380,1.824436402073870810,-0.834877726226893380,
+      0.333973874901496770,-0.646106479315673776,0.333973874901496770,1.871892825636887640,-0.893734096124207178,
+      0.272903880596429671,-0.513507745397738469,0.272903880596429671,1.918161772571113750,-0.950461788366234739,
+      0.053535383722369843,-0.069683422367188122,0.053535383722369843,1.948900719896301760,-0.986288064973853129 } };
+static const double zoom_fir_taps[4][4] = {
+    { 475.1179397144384210E-6, 0.503905202786044337, 0.503905202786044337, 475.1179397144384210E-6 },
+    { 0.198273254218889416, 0.298085149879260325, 0.298085149879260325, 0.198273254218889416 },
+    { 0.199820836596682871, 0.272777397353925699, 0.272777397353925699, 0.199820836596682871 },
+    { 0.199820836596682871, 0.272777397353925699, 0.272777397353925699, 0.199820836596682871 } };
 
 /* initAudioProcessor + ReinitAudioFilters + InitNotchFilter + InitAGC +
  * InitNoiseReduction + CWDecoder_Init + FFT state, all from power-on zeros */
@@ -190,6 +227,21 @@ int orc_audio_configure(orc_audio_t *s, const orc_audio_params_t *p)
     s->cw_limit = 50; s->cw_limit_low = 50;
     memset(s->cw_text, ' ', 15);
     s->cw_text[15] = 0;
+    if (p->fft_zoom > 1) { /* FFT_Init, fft.c:188-209 */
+        int zi;
+        switch (p->fft_zoom) { case 2: zi = 0; break; case 4: zi = 1; break; case 8: zi = 2; break;
+                               case 16: zi = 3; break; default: return -1; }
+        for (int i = 0; i < 20; i++) s->zoom_c[i] = (float)zoom_biquad[zi][i];
+        for (int i = 0; i < 4; i++) s->zoom_fir[i] = (float)zoom_fir_taps[zi][i];
+    }
+    s->alc_gain = 1.0f;
+    s->txfm_index = 2.0f; /* ModulateFM, audio_processor.c:597-606 */
+    switch (p->filter_width) {
+    case 5000: s->txfm_index = 2.0f; break; case 6000: s->txfm_index = 3.0f; break;
+    case 7000: s->txfm_index = 4.0f; break; case 8000: s->txfm_index = 5.0f; break;
+    case 9000: s->txfm_index = 6.0f; break; case 9500: s->txfm_index = 7.0f; break;
+    case 10000: s->txfm_index = 8.0f; break; case 15000: s->txfm_index = 9.0f; break;
+    case 0: s->txfm_index = 10.0f; break; default: break; }
     return 0;
 }
 
@@ -471,6 +523,131 @@ void orc_audio_status(const orc_audio_t *s, float *smeter_max, float *smeter_min
     *wpm = s->cw_wpm; *squelched = s->squelched;
 }
 
+/* ---- TX audio ------------------------------------------------------------------ */
+
+/* arm_fir_f32, 201 taps: y[n] = sum_k c[k] * x[n - 200 + k], one accumulator, k ascending */
+static void tx_fir(const float *c, float *hist, float *buf, int n)
+{
+    float ext[200 + SUB];
+    memcpy(ext, hist, 200 * sizeof(float));
+    memcpy(ext + 200, buf, n * sizeof(float));
+    for (int t = 0; t < n; t++) {
+        float acc = 0.0f;
+        for (int k = 0; k < 201; k++) acc += ext[t + k] * c[k];
+        buf[t] = acc;
+    }
+    memcpy(hist, ext + n, 200 * sizeof(float));
+}
+
+static uint32_t f2u_sat(float v)
+{
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+/* processTxAudio (audio_processor.c:61-273) on one 192-frame block.  mic_lr: the
+ * codec / USB samples (left, right) int16; iq_out: what FPGA_fpgadata_sendiq
+ * (fpga.c:403-436) puts on the bus, (I, Q) int16; loop_lr: the codec output of
+ * LOOPBACK mode (left, right) int32, zero otherwise.  The HPF/LPF lattices and
+ * their state are the RX ones, as in the firmware. */
+void orc_audio_tx_block(orc_audio_t *s, const int16_t *mic_lr, int16_t *iq_out, int32_t *loop_lr)
+{
+    float bi[BLOCK], bq[BLOCK];
+    const int m = s->p.mode, tune = s->p.tune;
+    float amp = s->p.rf_power / 100.0f * 31000.0f; /* MAX_TX_AMPLITUDE, settings.h:13 */
+    for (int i = 0; i < BLOCK; i++) {
+        if (tune) { bi[i] = amp; bq[i] = amp; }
+        else { bi[i] = (float)mic_lr[2 * i]; bq[i] = (float)mic_lr[2 * i + 1]; }
+    }
+    if (!tune) { dc_filter(s, bi, BLOCK, 2); dc_filter(s, bq, BLOCK, 3); }
+    if (m != MODE_IQ && !tune) {
+        for (int b = 0; b < BLOCK / SUB; b++) lattice_run(&s->hpf_i, bi + b * SUB, SUB);
+        if (s->p.filter_width > 0)
+            for (int b = 0; b < BLOCK / SUB; b++) lattice_run(&s->lpf_i, bi + b * SUB, SUB);
+        memcpy(bq, bi, sizeof bi);
+        float mx = 0;
+        for (int i = 0; i < BLOCK; i++) {
+            const float ai = fabsf(bi[i]), aq = fabsf(bq[i]);
+            if (ai > mx) mx = ai;
+            if (aq > mx) mx = aq;
+        }
+        if (mx == 0.0f) mx = 0.001f;
+        s->tx_max_amplitude = mx;
+        const float target = amp / mx;
+        if (target > s->alc_gain) s->alc_gain += (target - s->alc_gain) / 500.0f;
+        else s->alc_gain -= (s->alc_gain - target) / 500.0f;
+        if (target < s->alc_gain) s->alc_gain = target;
+        if (s->alc_gain < 0.0f) s->alc_gain = 0.0f;
+        if ((s->alc_gain * mx) > (amp * 1.1f)) s->alc_gain = target;
+        if (s->alc_gain > 500.0f) s->alc_gain = 500.0f;
+        if (mx < 15.0f) s->alc_gain = 0.0f;
+        if ((s->alc_gain > 1.0f) && (m == MODE_DIGI_L || m == MODE_DIGI_U || m == MODE_IQ || m == MODE_LOOPBACK))
+            s->alc_gain = 1.0f;
+        for (int i = 0; i < BLOCK; i++) { bi[i] = bi[i] * s->alc_gain; bq[i] = bq[i] * s->alc_gain; }
+        switch (m) {
+        case MODE_CW_L: case MODE_CW_U:
+            if (!s->p.key) amp = 0;
+            for (int i = 0; i < BLOCK; i++) { bq[i] = amp; bi[i] = amp; }
+            break;
+        case MODE_USB: case MODE_DIGI_U:
+            for (int b = 0; b < BLOCK / SUB; b++) {
+                tx_fir(tx_hilbert_q, s->tx_fir_q, bi + b * SUB, SUB);
+                tx_fir(tx_hilbert_i, s->tx_fir_i, bq + b * SUB, SUB);
+            }
+            break;
+        case MODE_LSB: case MODE_DIGI_L: case MODE_AM:
+            for (int b = 0; b < BLOCK / SUB; b++) {
+                tx_fir(tx_hilbert_i, s->tx_fir_i, bi + b * SUB, SUB);
+                tx_fir(tx_hilbert_q, s->tx_fir_q, bq + b * SUB, SUB);
+            }
+            if (m == MODE_AM)
+                for (int i = 0; i < BLOCK; i++) {
+                    const float i_am = ((bi[i] - bq[i]) + amp) / 2.0f;
+                    const float q_am = ((bq[i] - bi[i]) - amp) / 2.0f;
+                    bi[i] = i_am; bq[i] = q_am;
+                }
+            break;
+        case MODE_NFM: case MODE_WFM:
+            for (int i = 0; i < BLOCK; i++) { /* ModulateFM */
+                const float a = bi[i];
+                s->txfm_hpf_b = 0.95f * (s->txfm_hpf_b + a - s->txfm_hpf_a);
+                s->txfm_hpf_a = a;
+                s->txfm_accum = f2u_sat((float)s->txfm_accum + s->txfm_hpf_b);
+                s->txfm_accum %= 48000u;
+                const float sd = (s->txfm_accum / (float)48000) * PI_F * s->txfm_index;
+                bi[i] = amp * sinf(sd);
+                bq[i] = amp * cosf(sd);
+            }
+            break;
+        default: break;
+        }
+    }
+    if (s->p.mute && !tune)
+        for (int i = 0; i < BLOCK; i++) { bi[i] = bi[i] * 0; bq[i] = bq[i] * 0; }
+    if (m == MODE_LOOPBACK && !tune) {
+        const float vol = (float)s->p.volume / 50.0f;
+        for (int i = 0; i < BLOCK; i++) {
+            const int32_t v = f2i(bi[i] * vol);
+            loop_lr[2 * i] = v; loop_lr[2 * i + 1] = v;
+            iq_out[2 * i] = 0; iq_out[2 * i + 1] = 0;
+        }
+    } else
+        for (int i = 0; i < BLOCK; i++) {
+            iq_out[2 * i] = (int16_t)f2i(bi[i]);
+            iq_out[2 * i + 1] = (int16_t)f2i(bq[i]);
+            loop_lr[2 * i] = 0; loop_lr[2 * i + 1] = 0;
+        }
+}
+
+void orc_audio_tx_run(orc_audio_t *s, const int16_t *mic_lr, size_t n_frames, int16_t *iq_out, int32_t *loop_lr)
+{
+    for (size_t b = 0; b + BLOCK <= n_frames; b += BLOCK)
+        orc_audio_tx_block(s, mic_lr + 2 * b, iq_out + 2 * b, loop_lr + 2 * b);
+}
+
+float orc_audio_alc_gain(const orc_audio_t *s) { return s->alc_gain; }
+
 /* ---- FFT panadapter ---------------------------------------------------------- */
 static void fft512(double *re, double *im)
 {
@@ -492,6 +669,39 @@ static void fft512(double *re, double *im)
                 re[a] += xr; im[a] += xi;
             }
     }
+}
+
+/* arm_biquad_cascade_df1_f32, 4 stages, coefficients {b0,b1,b2,a1,a2} per stage,
+ * state {x[n-1], x[n-2], y[n-1], y[n-2]} per stage */
+static void zoom_biquad_run(const float *c, float *st, float *buf, int n)
+{
+    for (int sg = 0; sg < 4; sg++) {
+        const float b0 = c[5 * sg], b1 = c[5 * sg + 1], b2 = c[5 * sg + 2], a1 = c[5 * sg + 3], a2 = c[5 * sg + 4];
+        float x1 = st[4 * sg], x2 = st[4 * sg + 1], y1 = st[4 * sg + 2], y2 = st[4 * sg + 3];
+        for (int i = 0; i < n; i++) {
+            const float x = buf[i];
+            const float acc = (b0 * x) + (b1 * x1) + (b2 * x2) + (a1 * y1) + (a2 * y2);
+            x2 = x1; x1 = x; y2 = y1; y1 = acc;
+            buf[i] = acc;
+        }
+        st[4 * sg] = x1; st[4 * sg + 1] = x2; st[4 * sg + 2] = y1; st[4 * sg + 3] = y2;
+    }
+}
+
+/* arm_fir_decimate_f32, 4 taps, factor M, in place: out[m] = sum_k c[k] * x[m*M - 3 + k]
+ * (the state window of output m ends at the first of its M new samples) */
+static void zoom_decimate(const float *c, float *hist, float *buf, int n, int M)
+{
+    float ext[3 + FFT_SIZE];
+    memcpy(ext, hist, 3 * sizeof(float));
+    memcpy(ext + 3, buf, n * sizeof(float));
+    for (int m = 0; m < n / M; m++) {
+        const float *x = ext + m * M;
+        float acc = 0.0f;
+        for (int k = 0; k < 4; k++) acc += x[k] * c[k];
+        buf[m] = acc;
+    }
+    memcpy(hist, ext + n, 3 * sizeof(float));
 }
 
 /* getFFTColor (fft.c:506-539) + rgb888torgb565 */
@@ -526,6 +736,19 @@ void orc_fft_frame(orc_audio_t *s, const int16_t *spec_iq, float *bins, uint16_t
     dc_filter(s, fi, FFT_SIZE, 4);
     dc_filter(s, fq, FFT_SIZE, 5);
     if (s->p.notch) { biquad_run(&s->notch_fft_i, fi, FFT_SIZE); biquad_run(&s->notch_fft_q, fq, FFT_SIZE); }
+    if (s->p.fft_zoom > 1) { /* fft.c:236-261 */
+        const int M = s->p.fft_zoom, zw = FFT_SIZE / M;
+        zoom_biquad_run(s->zoom_c, s->zoom_bq_i, fi, FFT_SIZE);
+        zoom_biquad_run(s->zoom_c, s->zoom_bq_q, fq, FFT_SIZE);
+        zoom_decimate(s->zoom_fir, s->zoom_dec_i, fi, FFT_SIZE, M);
+        zoom_decimate(s->zoom_fir, s->zoom_dec_q, fq, FFT_SIZE, M);
+        memmove(s->zoom_buf, s->zoom_buf + 2 * zw, sizeof(float) * 2 * (FFT_SIZE - zw));
+        for (int i = 0; i < zw; i++) {
+            s->zoom_buf[2 * (FFT_SIZE - zw + i)] = fi[i];
+            s->zoom_buf[2 * (FFT_SIZE - zw + i) + 1] = fq[i];
+        }
+        for (int i = 0; i < FFT_SIZE; i++) { fi[i] = s->zoom_buf[2 * i]; fq[i] = s->zoom_buf[2 * i + 1]; }
+    }
     double re[FFT_SIZE], im[FFT_SIZE];
     for (int i = 0; i < FFT_SIZE; i++) {
         const float w = 0.54f - 0.46f * cosf((2.0f * PI_F * i) / ((float)FFT_SIZE - 1.0f));

@@ -316,6 +316,7 @@ class AudioParams(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("agc", C.c_uint8), ("dnr", C.c_uint8), ("notch", C.c_uint8),
                 ("mute", C.c_uint8), ("cw_decoder", C.c_uint8), ("fm_sql_threshold", C.c_uint8),
                 ("volume", C.c_uint8), ("iq_swap", C.c_uint8), ("fft_averaging", C.c_uint8),
+                ("fft_zoom", C.c_uint8), ("rf_power", C.c_uint8), ("tune", C.c_uint8), ("key", C.c_uint8),
                 ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("filter_width", C.c_uint16),
                 ("hpf_pass", C.c_uint16), ("notch_fc", C.c_uint16), ("agc_speed", C.c_uint16),
                 ("rf_gain", C.c_float)]
@@ -323,10 +324,10 @@ class AudioParams(C.Structure):
 
 def audio_params(mode="USB", agc=1, dnr=0, notch=0, mute=0, cw_decoder=0, fm_sql_threshold=0, volume=50,
                  iq_swap=0, fft_averaging=4, filter_width=2700, hpf_pass=300, notch_fc=1000, agc_speed=3,
-                 rf_gain=50.0):
+                 rf_gain=50.0, fft_zoom=1, rf_power=50, tune=0, key=0):
     return AudioParams(MODES[mode] if isinstance(mode, str) else mode, agc, dnr, notch, mute, cw_decoder,
-                       fm_sql_threshold, volume, iq_swap, fft_averaging, 0, 0, filter_width, hpf_pass,
-                       notch_fc, agc_speed, rf_gain)
+                       fm_sql_threshold, volume, iq_swap, fft_averaging, fft_zoom, rf_power, tune, key, 0, 0,
+                       filter_width, hpf_pass, notch_fc, agc_speed, rf_gain)
 
 
 class Audio:
@@ -355,6 +356,21 @@ class Audio:
         lib().orc_audio_status(self.buf, C.byref(mx), C.byref(mn), C.byref(g), text, C.byref(wpm), C.byref(sq))
         return {"smeter_max": mx.value, "smeter_min": mn.value, "agc_gain": g.value,
                 "cw_text": text.value.decode("ascii", "replace"), "cw_wpm": wpm.value, "squelched": bool(sq.value)}
+
+    def tx(self, mic_lr):
+        """processTxAudio over n frames (n % 192 == 0): returns (iq int16 [n][2], loopback int32 [n][2])."""
+        mic = np.ascontiguousarray(mic_lr, dtype=np.int16).reshape(-1, 2)
+        n = mic.shape[0]
+        assert n % 192 == 0
+        iq = np.zeros((n, 2), np.int16)
+        loop = np.zeros((n, 2), np.int32)
+        lib().orc_audio_tx_run(self.buf, _p(mic), C.c_size_t(n), _p(iq), _p(loop))
+        return iq, loop
+
+    def alc_gain(self):
+        f = lib().orc_audio_alc_gain
+        f.restype = C.c_float
+        return float(f(self.buf))
 
     def fft(self, spec_iq):
         spec = np.ascontiguousarray(spec_iq, dtype=np.int16).reshape(-1, 2)

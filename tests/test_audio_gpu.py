@@ -170,3 +170,123 @@ def test_fft_frames_within_tolerance(ddc, orc):
             mismatched_pixels += int((rows[c, f] != wr).sum())
     assert mismatched_pixels <= 0.002 * n_ch * frames * 256
     assert (rows[0, -1] >> 11).max() == 31  # something red on the carrier
+
+
+def mic_signal(n, seed):
+    r = np.random.default_rng(seed)
+    t = np.arange(n) / sig.FS
+    x = 2500.0 * np.sin(2 * np.pi * r.uniform(300, 2500) * t) + 900.0 * np.sin(2 * np.pi * r.uniform(300, 2500) * t)
+    x *= 1.0 + 0.5 * np.sin(2 * np.pi * 2.3 * t)
+    l = sig.quantise(x + r.normal(0, 20, n))
+    rr = sig.quantise(0.5 * x + r.normal(0, 20, n))
+    return np.stack([l, rr], axis=1)
+
+
+TX_EXACT = [
+    dict(mode="USB", rf_power=50), dict(mode="LSB", rf_power=100, hpf_pass=100, filter_width=3000),
+    dict(mode="DIGI_U", rf_power=30, filter_width=0), dict(mode="DIGI_L", rf_power=70),
+    dict(mode="AM", rf_power=50, filter_width=6000), dict(mode="CW_U", rf_power=40, key=1),
+    dict(mode="CW_L", rf_power=40, key=0), dict(mode="IQ", rf_power=50), dict(mode="LOOPBACK", volume=70),
+    dict(mode="USB", rf_power=50, tune=1), dict(mode="USB", rf_power=50, mute=1),
+]
+
+
+def test_tx_audio_bit_exact(ddc, orc):
+    n = 192 * 30
+    n_ch = len(TX_EXACT)
+    mic = np.stack([mic_signal(n, 300 + c) for c in range(n_ch)])
+    d = ddc.Ddc(n_ch)
+    for c, kw in enumerate(TX_EXACT):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    # two calls: the FIR delay lines, lattices and ALC gain carry over
+    iq1, lp1 = d.audio_tx_process(mic[:, :192 * 11])
+    iq2, lp2 = d.audio_tx_process(mic[:, 192 * 11:])
+    iq, lp = np.concatenate([iq1, iq2], axis=1), np.concatenate([lp1, lp2], axis=1)
+    for c, kw in enumerate(TX_EXACT):
+        a = orc.Audio(orc.audio_params(**kw))
+        wiq, wlp = a.tx(mic[c])
+        assert np.array_equal(iq[c], wiq), "case %d %r: first diff at %s" % (c, kw, np.argwhere(iq[c] != wiq)[:3])
+        assert np.array_equal(lp[c], wlp), "case %d %r loopback" % (c, kw)
+        assert d.audio_status(c)["alc_gain"] == a.alc_gain()
+    assert np.abs(iq[0]).max() > 1000
+
+
+def test_tx_fm_within_one_lsb(ddc, orc):
+    # sinf / cosf of the device library vs libm: +-2 LSB of the 16-bit bus word
+    n = 192 * 30
+    cases = [dict(mode="NFM", rf_power=60, filter_width=0), dict(mode="WFM", rf_power=100, filter_width=15000),
+             dict(mode="NFM", rf_power=20, filter_width=8000)]
+    mic = np.stack([mic_signal(n, 400 + c) for c in range(3)])
+    d = ddc.Ddc(3)
+    for c, kw in enumerate(cases):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    iq, _ = d.audio_tx_process(mic)
+    for c, kw in enumerate(cases):
+        wiq, _ = orc.Audio(orc.audio_params(**kw)).tx(mic[c])
+        assert np.abs(iq[c].astype(np.int32) - wiq.astype(np.int32)).max() <= 2, "case %d" % c
+
+
+@pytest.mark.parametrize("zoom", [2, 4, 8, 16])
+def test_fft_zoom_within_tolerance(ddc, orc, zoom):
+    n_ch, frames = 3, 20
+    n = 512 * frames
+    r = np.random.default_rng(17 + zoom)
+    spec = np.stack([
+        sig.quantise(sig.tone_iq(n, 700.0, 900.0) + r.normal(0, 10, (n, 2))),
+        sig.quantise(r.normal(0, 2000.0, (n, 2))),
+        sig.noisy_two_tone(n, 47, amp=1500.0),
+    ])
+    kw = dict(fft_zoom=zoom, fft_averaging=2)
+    d = ddc.Ddc(n_ch)
+    d.audio_configure(ddc.audio_params(**kw))
+    b1, r1 = d.fft_process(spec[:, :512 * 7])
+    b2, r2 = d.fft_process(spec[:, 512 * 7:])
+    bins, rows = np.concatenate([b1, b2], axis=1), np.concatenate([r1, r2], axis=1)
+    bad = 0
+    for c in range(n_ch):
+        a = orc.Audio(orc.audio_params(**kw))
+        for f in range(frames):
+            wb, wr, _ = a.fft(spec[c, 512 * f:512 * (f + 1)])
+            assert np.abs(bins[c, f] - wb).max() <= 1e-4 * max(float(wb.max()), 1e-3), "ch %d frame %d" % (c, f)
+            bad += int((rows[c, f] != wr).sum())
+    assert bad <= 0.002 * n_ch * frames * 256
+
+
+def test_fft_mixed_zoom_is_rejected(ddc):
+    d = ddc.Ddc(2)
+    d.audio_configure(ddc.audio_params(fft_zoom=1), 0)
+    d.audio_configure(ddc.audio_params(fft_zoom=4), 1)
+    with pytest.raises(ddc.DdcError):
+        d.fft_process(np.zeros((2, 512, 2), np.int16))
+    with pytest.raises(ddc.DdcError):
+        d.audio_configure(ddc.audio_params(fft_zoom=3))
+
+
+def test_full_chain_adc_to_audio(ddc, orc):
+    """Config-2 shape at test size: packed ADC -> DDC -> USB demodulation, and the
+    TX return path mic -> I/Q -> DUC, every stage against the oracle."""
+    samples = 1024 * 192 * 3
+    freq = 7100000
+    phi, _ = ddc.phrase_from_frequency(freq)
+    n = np.arange(samples)
+    r = np.random.default_rng(5)
+    adc = np.clip(np.rint(900 * np.sin(2 * np.pi * (freq + 1500.0) * n / 49152000.0) +
+                          r.integers(-40, 40, samples)), -2047, 2047).astype(np.int16)
+    d = ddc.Ddc(1)
+    d.tune(0, phi)
+    kw = dict(mode="USB", filter_width=2700, hpf_pass=300, agc=1, dnr=0)
+    d.audio_configure(ddc.audio_params(**kw))
+    spec, voice = d.rx_process(ddc.pack_adc12(adc)[None], samples)
+    audio = d.audio_rx_process(spec, voice)
+    ws, wv = orc.RxChain(phi).run(adc)
+    assert np.array_equal(spec[0], ws) and np.array_equal(voice[0], wv)
+    a = orc.Audio(orc.audio_params(**kw))
+    assert np.array_equal(audio[0], a.rx(ws, wv))
+    assert np.abs(audio[0][192:]).max() > 100
+    # TX: two blocks of microphone -> I/Q -> DAC words
+    mic = mic_signal(192 * 2, 9)[None]
+    iq, _ = d.audio_tx_process(mic)
+    wiq, _ = a.tx(mic[0])
+    assert np.array_equal(iq[0], wiq)
+    dac = d.tx_process(iq[:, :8])
+    assert np.array_equal(dac[0], orc.TxChain(phi).run(wiq[:8]))

@@ -258,3 +258,140 @@ def test_unknown_filter_rejected(orc):
         orc.Audio(orc.audio_params(filter_width=1234))
     with pytest.raises(ValueError):
         orc.Audio(orc.audio_params(mode="USB", hpf_pass=60))
+
+
+# ---- TX audio (processTxAudio) ------------------------------------------------
+
+def mic_tone(n, f_hz, amp):
+    t = np.arange(n) / sig.FS
+    x = sig.quantise(amp * np.sin(2 * np.pi * f_hz * t))
+    return np.stack([x, x], axis=1)
+
+
+def sideband_power(iq, f_hz):
+    z = iq[:, 0].astype(np.float64) + 1j * iq[:, 1].astype(np.float64)
+    n = len(z)
+    sp = np.abs(np.fft.fft(z * np.hanning(n))) ** 2
+    k = int(round(f_hz * n / sig.FS))
+    up = sp[k - 3:k + 4].sum()
+    dn = sp[n - k - 3:n - k + 4].sum()
+    return up, dn
+
+
+@pytest.mark.parametrize("mode,upper", [("USB", True), ("LSB", False), ("DIGI_U", True), ("DIGI_L", False)])
+def test_tx_ssb_suppresses_the_other_sideband(orc, mode, upper):
+    n = 192 * 150
+    a = orc.Audio(orc.audio_params(mode=mode, rf_power=50, filter_width=2700, hpf_pass=300))
+    iq, loop = a.tx(mic_tone(n, 1200.0, 3000.0))
+    up, dn = sideband_power(iq[n // 2:], 1200.0)
+    want, other = (up, dn) if upper else (dn, up)
+    # the +-45 degree pair sums to one sideband; which sign is "upper" on the air is
+    # fixed by the FPGA mixer, here only the >40 dB asymmetry and its flip are pinned
+    assert max(want, other) > 1e4 * min(want, other)
+    assert not loop.any()
+    test_tx_ssb_suppresses_the_other_sideband.seen = getattr(test_tx_ssb_suppresses_the_other_sideband, "seen", {})
+    test_tx_ssb_suppresses_the_other_sideband.seen[mode] = up > dn
+    seen = test_tx_ssb_suppresses_the_other_sideband.seen
+    if "USB" in seen and "LSB" in seen:
+        assert seen["USB"] != seen["LSB"]
+
+
+def test_tx_alc_levels_to_rf_power(orc):
+    # the compressor walks 1/500 of the way to rf_amplitude / peak per block
+    # (TX_AGC_STEPSIZE, audio_processor.c:124-129)
+    blocks = 400
+    n = 192 * blocks
+    a = orc.Audio(orc.audio_params(mode="USB", rf_power=50))
+    iq, _ = a.tx(mic_tone(n, 1000.0, 2000.0))
+    target = 15500.0 / 2000.0
+    want = target - (target - 1.0) * (1.0 - 1.0 / 500.0) ** blocks
+    assert abs(a.alc_gain() - want) < 0.05 * want
+    env = np.hypot(iq[-192 * 20:, 0].astype(np.float64), iq[-192 * 20:, 1].astype(np.float64))
+    assert abs(np.median(env) - want * 2000.0) < 0.1 * want * 2000.0
+    # ... and never overshoots the selected amplitude once it has arrived
+    a = orc.Audio(orc.audio_params(mode="USB", rf_power=50))
+    iq, _ = a.tx(mic_tone(192 * 3000, 1000.0, 2000.0))
+    env = np.hypot(iq[-192 * 20:, 0].astype(np.float64), iq[-192 * 20:, 1].astype(np.float64))
+    assert 0.9 * 15500 < env.max() < 1.15 * 15500
+
+
+def test_tx_alc_noise_gate_and_digi_cap(orc):
+    n = 192 * 10
+    a = orc.Audio(orc.audio_params(mode="USB", rf_power=100))
+    iq, _ = a.tx(mic_tone(n, 1000.0, 5.0))  # below TX_AGC_NOISEGATE 15
+    assert a.alc_gain() == 0.0 and not iq[192:].any()
+    a = orc.Audio(orc.audio_params(mode="DIGI_U", rf_power=100, filter_width=0))
+    a.tx(mic_tone(192 * 50, 1000.0, 100.0))
+    assert a.alc_gain() == 1.0
+
+
+def test_tx_cw_tune_and_mute(orc):
+    mic = mic_tone(192 * 2, 700.0, 1000.0)
+    amp = int(np.float32(np.float32(np.float32(40) / np.float32(100.0)) * np.float32(31000.0)))
+    a = orc.Audio(orc.audio_params(mode="CW_U", rf_power=40, key=1))
+    iq, _ = a.tx(mic)
+    assert (iq == amp).all()
+    a = orc.Audio(orc.audio_params(mode="CW_U", rf_power=40, key=0))
+    assert not a.tx(mic)[0].any()
+    a = orc.Audio(orc.audio_params(mode="LSB", rf_power=40, tune=1, mute=1))
+    assert (a.tx(mic)[0] == amp).all()  # tune overrides mute and the modulator
+    a = orc.Audio(orc.audio_params(mode="USB", rf_power=40, mute=1))
+    assert not a.tx(mic)[0].any()
+
+
+def test_tx_am_has_carrier_and_envelope(orc):
+    n = 192 * 300
+    a = orc.Audio(orc.audio_params(mode="AM", rf_power=50, filter_width=6000))
+    iq, _ = a.tx(mic_tone(n, 1000.0, 2000.0))
+    z = iq[n // 2:, 0].astype(np.float64) + 1j * iq[n // 2:, 1].astype(np.float64)
+    carrier = abs(z.mean())
+    assert abs(carrier - 15500.0 / np.sqrt(2)) < 0.05 * 15500.0  # (amp/2, -amp/2)
+    env = np.abs(z)
+    assert env.max() > 1.5 * carrier and env.min() < 0.5 * carrier
+
+
+def test_tx_fm_constant_envelope(orc):
+    n = 192 * 50
+    a = orc.Audio(orc.audio_params(mode="NFM", rf_power=60, filter_width=0))
+    iq, _ = a.tx(mic_tone(n, 800.0, 3000.0))
+    env = np.hypot(iq[192:, 0].astype(np.float64), iq[192:, 1].astype(np.float64))
+    assert np.abs(env - 18600.0).max() < 2.0
+    assert iq[192:, 0].std() > 1000  # the phase actually moves
+
+
+def test_tx_loopback_goes_to_codec(orc):
+    n = 192 * 20
+    a = orc.Audio(orc.audio_params(mode="LOOPBACK", rf_power=50, volume=50))
+    iq, loop = a.tx(mic_tone(n, 1000.0, 1000.0))
+    assert not iq.any()
+    assert np.array_equal(loop[:, 0], loop[:, 1]) and np.abs(loop[192 * 10:]).max() > 500
+
+
+def test_tx_iq_mode_passes_dc_blocked_stereo(orc):
+    n = 192
+    mic = np.stack([np.full(n, 1000, np.int16), np.full(n, -700, np.int16)], axis=1)
+    a = orc.Audio(orc.audio_params(mode="IQ"))
+    iq, _ = a.tx(mic)
+    assert iq[0, 0] == 1000 and iq[0, 1] == -700
+    assert 0 < iq[-1, 0] < 1000 and -700 < iq[-1, 1] < 0
+
+
+# ---- zoom FFT -------------------------------------------------------------------
+
+@pytest.mark.parametrize("zoom", [2, 4, 8, 16])
+def test_fft_zoom_spreads_the_spectrum(orc, zoom):
+    f = 600.0
+    frames = 8 * zoom + 8
+    x = sig.quantise(sig.tone_iq(512 * frames, f, 800.0))
+    a = orc.Audio(orc.audio_params(fft_zoom=zoom, fft_averaging=1))
+    for k in range(frames):
+        bins, row, hts = a.fft(x[512 * k:512 * (k + 1)])
+    # bin spacing after decimation by M is 48000 / M / 512 per FFT bin, two FFT bins per output bin
+    want = f * zoom * 512 / sig.FS / 2
+    assert abs(int(np.argmax(bins)) - want) <= 1
+    # out-of-band tone is removed by the zoom low-pass
+    y = sig.quantise(sig.tone_iq(512 * frames, 0.45 * sig.FS, 800.0))
+    b = orc.Audio(orc.audio_params(fft_zoom=zoom, fft_averaging=1))
+    for k in range(frames):
+        bins2, _, _ = b.fft(y[512 * k:512 * (k + 1)])
+    assert bins2.max() < 0.05 * bins.max()

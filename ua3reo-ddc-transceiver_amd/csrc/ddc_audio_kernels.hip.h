@@ -11,7 +11,8 @@
  *   DoAGC                          STM32/Src/agc.c:21-67
  *   CWDecoder_Process              STM32/Src/cw_decoder.c:56-174 (millisecond clock = 4 ms per block)
  *   output stage                   STM32/Src/audio_processor.c:364-394
- *   FFT_doFFT + row mapping        STM32/Src/fft.c:212-331, :361-379, :506-539
+ *   FFT_doFFT + row mapping        STM32/Src/fft.c:212-331, :361-379, :506-539 (zoom branch :236-261)
+ *   processTxAudio / ModulateFM    STM32/Src/audio_processor.c:61-273, :590-619
  *
  * All of it is recursion in time (IIR lattices, LMS, AGC, squelch), so the only
  * parallel axis is the channel: one thread walks one channel, block by block of
@@ -59,6 +60,24 @@ struct AudioState {
     uint32_t blocks;
     float fft_mean[256], fft_max_value;
     uint32_t fft_max_errors;
+};
+
+/* Zoom-FFT state of one channel (fft.c:44-209): 4-stage DF1 biquad low-pass,
+ * 4-tap FIR decimator, and the tail of the decimated stream that the next
+ * frame's sliding 512-sample window starts with. */
+struct ZoomState {
+    float c[20], fir[4];
+    float bq_i[16], bq_q[16];
+    float dec_i[3], dec_q[3];
+    uint32_t zoom, pad;
+    float2 hist[512];
+};
+
+/* TX-only state of one channel: Hilbert FIR delay lines, ALC gain, FM modulator. */
+struct TxAudioState {
+    float fir_i[200], fir_q[200];
+    float alc_gain, fm_hpf_a, fm_hpf_b, fm_index, max_amplitude;
+    uint32_t fm_accum;
 };
 
 __device__ __forceinline__ void lattice_step(Lattice &s, int n, const float *k, const float *v, float &x)
@@ -389,22 +408,38 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
 /* ---- FFT panadapter ---------------------------------------------------------- */
 
 /* Pass A (thread = channel): DC filter and optional notch over the call's frames
- * of 512 SPEC samples, in sequence; float I/Q to work: [channel][n][2]. */
-__global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__ states, uint32_t n_ch,
-                                                        const int16_t *__restrict__ spec_iq, uint32_t n,
-                                                        float2 *__restrict__ work)
+ * of 512 SPEC samples, in sequence.  Without zoom the float I/Q go to
+ * work[channel][n]; with zoom M the stream is low-passed (4 biquads), decimated
+ * by M (4-tap FIR) and appended behind the 512 - 512/M samples kept from earlier
+ * frames: work[channel][512 - 512/M + n/M], where FFT frame f is the 512 samples
+ * starting at f * 512/M (the firmware's sliding FFTInput_ZOOMFFT buffer). */
+__global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__ states, ZoomState *__restrict__ zooms,
+                                                        uint32_t n_ch, const int16_t *__restrict__ spec_iq, uint32_t n,
+                                                        float2 *__restrict__ work, uint32_t work_pitch)
 {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
     AudioState &s = states[ch];
+    ZoomState &z = zooms[ch];
     float dx4 = s.dc_x[4], dy4 = s.dc_y[4], dx5 = s.dc_x[5], dy5 = s.dc_y[5];
     float ni[2] = { s.notch_fi[0], s.notch_fi[1] }, nq[2] = { s.notch_fq[0], s.notch_fq[1] };
     float c[5];
     for (int i = 0; i < 5; i++) c[i] = s.notch_c[i];
     const bool notch = s.p.notch, swap = s.p.iq_swap;
+    const uint32_t M = z.zoom > 1 ? z.zoom : 1;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(spec_iq) + (size_t)ch * n;
-    float2 *dst = work + (size_t)ch * n;
+    float2 *dst = work + (size_t)ch * work_pitch;
     const float A1 = 0.99951171875f;
+    float zc[20], zf[4], bi[16], bq[16], wi[4], wq[4]; // wi/wq: the newest four low-passed samples
+    uint32_t keep = 0;
+    if (M > 1) {
+        for (int i = 0; i < 20; i++) zc[i] = z.c[i];
+        for (int i = 0; i < 4; i++) zf[i] = z.fir[i];
+        for (int i = 0; i < 16; i++) { bi[i] = z.bq_i[i]; bq[i] = z.bq_q[i]; }
+        for (int i = 0; i < 3; i++) { wi[i + 1] = z.dec_i[i]; wq[i + 1] = z.dec_q[i]; }
+        keep = 512 - 512 / M;
+        for (uint32_t i = 0; i < keep; i++) dst[i] = z.hist[i];
+    }
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t v = src[i];
         float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
@@ -412,10 +447,34 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
         { const float d = fi - dx4; const float a = A1 * dy4; const float o = d + a; dx4 = fi; dy4 = o; fi = o; }
         { const float d = fq - dx5; const float a = A1 * dy5; const float o = d + a; dx5 = fq; dy5 = o; fq = o; }
         if (notch) { fi = biquad_step(c, ni, fi); fq = biquad_step(c, nq, fq); }
-        dst[i] = make_float2(fi, fq);
+        if (M == 1) { dst[i] = make_float2(fi, fq); continue; }
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) { // arm_biquad_cascade_df1_f32: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2
+            const float b0 = zc[5 * sg], b1 = zc[5 * sg + 1], b2 = zc[5 * sg + 2], a1 = zc[5 * sg + 3], a2 = zc[5 * sg + 4];
+            const float yi = (b0 * fi) + (b1 * bi[4 * sg]) + (b2 * bi[4 * sg + 1]) + (a1 * bi[4 * sg + 2]) + (a2 * bi[4 * sg + 3]);
+            bi[4 * sg + 1] = bi[4 * sg]; bi[4 * sg] = fi; bi[4 * sg + 3] = bi[4 * sg + 2]; bi[4 * sg + 2] = yi;
+            fi = yi;
+            const float yq = (b0 * fq) + (b1 * bq[4 * sg]) + (b2 * bq[4 * sg + 1]) + (a1 * bq[4 * sg + 2]) + (a2 * bq[4 * sg + 3]);
+            bq[4 * sg + 1] = bq[4 * sg]; bq[4 * sg] = fq; bq[4 * sg + 3] = bq[4 * sg + 2]; bq[4 * sg + 2] = yq;
+            fq = yq;
+        }
+        wi[0] = wi[1]; wi[1] = wi[2]; wi[2] = wi[3]; wi[3] = fi;
+        wq[0] = wq[1]; wq[1] = wq[2]; wq[2] = wq[3]; wq[3] = fq;
+        if (i % M == 0) { // arm_fir_decimate_f32: the window of output m ends at sample m * M
+            float ai = 0.0f, aq = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ai += wi[k] * zf[k]; aq += wq[k] * zf[k]; }
+            dst[keep + i / M] = make_float2(ai, aq);
+        }
     }
     s.dc_x[4] = dx4; s.dc_y[4] = dy4; s.dc_x[5] = dx5; s.dc_y[5] = dy5;
     s.notch_fi[0] = ni[0]; s.notch_fi[1] = ni[1]; s.notch_fq[0] = nq[0]; s.notch_fq[1] = nq[1];
+    if (M > 1) {
+        for (int i = 0; i < 16; i++) { z.bq_i[i] = bi[i]; z.bq_q[i] = bq[i]; }
+        for (int i = 0; i < 3; i++) { z.dec_i[i] = wi[i + 1]; z.dec_q[i] = wq[i + 1]; }
+        const uint32_t produced = n / M;
+        for (uint32_t i = 0; i < keep; i++) z.hist[i] = dst[produced + i];
+    }
 }
 
 __constant__ float c_fft_window[512]; // 0.54 - 0.46 cos(2 pi i / 511)
@@ -425,11 +484,13 @@ __constant__ float2 c_fft_twiddle[256]; // exp(-2 pi i k / 512)
  * radix-2 FFT in LDS, magnitude, 2:1 bin average, bin 0 := bin 1.
  * mags: [channel][frames][256]. */
 __global__ __launch_bounds__(64) void ddc_fft_frames(const float2 *__restrict__ work, uint32_t frames_per_ch,
+                                                     uint32_t work_pitch, uint32_t frame_step,
                                                      float *__restrict__ mags)
 {
     __shared__ float re[512], im[512];
     const uint32_t fr = blockIdx.x, t = threadIdx.x;
-    const float2 *x = work + (size_t)fr * 512;
+    const uint32_t ch = fr / frames_per_ch, f = fr - ch * frames_per_ch;
+    const float2 *x = work + (size_t)ch * work_pitch + (size_t)f * frame_step;
     for (int j = 0; j < 8; j++) {
         const int i = t + 64 * j;
         const int r = (int)(__brev((unsigned)i) >> 23); // 9-bit reversal
@@ -462,7 +523,6 @@ __global__ __launch_bounds__(64) void ddc_fft_frames(const float2 *__restrict__ 
     }
     __syncthreads();
     if (t == 0) out[0] = out[1];
-    (void)frames_per_ch;
 }
 
 __device__ inline uint16_t fft_color(int height)
@@ -540,6 +600,153 @@ __global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ st
     }
     s.fft_mean[x] = mean;
     if (x == 0) { s.fft_max_value = max_value; s.fft_max_errors = max_errors; }
+}
+
+/* ---- TX audio -------------------------------------------------------------------- */
+
+__device__ __forceinline__ uint32_t f2u_sat(float v)
+{
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+__constant__ float c_tx_hilbert[2][201]; // [0] = +45 degree (I) taps, [1] = -45 degree (Q) taps
+
+/* arm_fir_f32, 201 taps, one accumulator, taps in ascending order; ext holds the
+ * 200 samples before the sub-block followed by its 64 samples */
+__device__ inline void tx_fir_block(const float *taps, float *hist, float *buf)
+{
+    float ext[200 + kASub];
+    for (int i = 0; i < 200; i++) ext[i] = hist[i];
+    for (int i = 0; i < kASub; i++) ext[200 + i] = buf[i];
+    for (int t = 0; t < kASub; t++) {
+        float acc = 0.0f;
+        for (int k = 0; k < 201; k++) acc += ext[t + k] * taps[k];
+        buf[t] = acc;
+    }
+    for (int i = 0; i < 200; i++) hist[i] = ext[kASub + i];
+}
+
+/*
+ * processTxAudio for every channel: thread = channel, sequential over blocks of
+ * 192 frames.  mic_lr: [channel][n_frames][2] int16 (left, right); iq_out:
+ * [channel][n_frames][2] int16 (I, Q) as FPGA_fpgadata_sendiq narrows them
+ * (fpga.c:403-436); loop_lr: [channel][n_frames][2] int32, the codec output of
+ * LOOPBACK mode (zero in every other mode), may be null.  The HPF / LPF lattice
+ * instances and DC-blocker slots are the firmware's shared ones (IIR_HPF_I,
+ * IIR_LPF_I, slots 2 and 3).
+ */
+__global__ __launch_bounds__(64) void ddc_audio_tx(AudioState *__restrict__ states, TxAudioState *__restrict__ txs,
+                                                   uint32_t n_ch, const int16_t *__restrict__ mic_lr, uint32_t n_frames,
+                                                   int16_t *__restrict__ iq_out, int32_t *__restrict__ loop_lr)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_ch) return;
+    AudioState &s = states[ch];
+    TxAudioState &x = txs[ch];
+    const ddc_audio_params p = s.p;
+    const int m = p.mode;
+    const bool tune = p.tune != 0;
+    const float amp0 = p.rf_power / 100.0f * 31000.0f; // MAX_TX_AMPLITUDE, settings.h:13
+    Lattice hpf = s.hpf_i, lpf = s.lpf_i;
+    const float *lk = ddc_lpf_k[s.lpf_idx], *lv = ddc_lpf_v[s.lpf_idx];
+    const float *hk = ddc_hpf_k[s.hpf_idx], *hv = ddc_hpf_v[s.hpf_idx];
+    const int lpf_n = s.lpf_n;
+    float alc = x.alc_gain, fa = x.fm_hpf_a, fb = x.fm_hpf_b, mxa = x.max_amplitude;
+    uint32_t facc = x.fm_accum;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(mic_lr) + (size_t)ch * n_frames;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(iq_out) + (size_t)ch * n_frames;
+    int32_t *lp = loop_lr ? loop_lr + (size_t)ch * n_frames * 2 : nullptr;
+    float bi[kABlock], bq[kABlock];
+    for (uint32_t b0 = 0; b0 + kABlock <= n_frames; b0 += kABlock) {
+        float amp = amp0;
+        for (int i = 0; i < kABlock; i++) {
+            if (tune) { bi[i] = amp; bq[i] = amp; continue; }
+            const uint32_t v = src[b0 + i];
+            float fi = dc_step(s, 2, (float)(int16_t)(v & 0xFFFFu));
+            const float fq = dc_step(s, 3, (float)((int32_t)v >> 16));
+            if (m != DDC_MODE_IQ) {
+                lattice_step(hpf, 6, hk, hv, fi);
+                if (p.filter_width > 0) lattice_step(lpf, lpf_n, lk, lv, fi);
+                bi[i] = fi; bq[i] = fi;
+            } else { bi[i] = fi; bq[i] = fq; }
+        }
+        if (m != DDC_MODE_IQ && !tune) {
+            float mx = 0;
+            for (int i = 0; i < kABlock; i++) {
+                const float a = fabsf(bi[i]);
+                if (a > mx) mx = a;
+            }
+            if (mx == 0.0f) mx = 0.001f;
+            mxa = mx;
+            const float target = amp / mx;
+            if (target > alc) alc += (target - alc) / 500.0f;
+            else alc -= (alc - target) / 500.0f;
+            if (target < alc) alc = target;
+            if (alc < 0.0f) alc = 0.0f;
+            if ((alc * mx) > (amp * 1.1f)) alc = target;
+            if (alc > 500.0f) alc = 500.0f;
+            if (mx < 15.0f) alc = 0.0f;
+            if ((alc > 1.0f) && (m == DDC_MODE_DIGI_L || m == DDC_MODE_DIGI_U || m == DDC_MODE_LOOPBACK)) alc = 1.0f;
+            for (int i = 0; i < kABlock; i++) { bi[i] = bi[i] * alc; bq[i] = bq[i] * alc; }
+            switch (m) {
+            case DDC_MODE_CW_L: case DDC_MODE_CW_U:
+                if (!p.key) amp = 0;
+                for (int i = 0; i < kABlock; i++) { bi[i] = amp; bq[i] = amp; }
+                break;
+            case DDC_MODE_USB: case DDC_MODE_DIGI_U:
+                for (int sb = 0; sb < kABlock / kASub; sb++) {
+                    tx_fir_block(c_tx_hilbert[1], x.fir_q, bi + sb * kASub);
+                    tx_fir_block(c_tx_hilbert[0], x.fir_i, bq + sb * kASub);
+                }
+                break;
+            case DDC_MODE_LSB: case DDC_MODE_DIGI_L: case DDC_MODE_AM:
+                for (int sb = 0; sb < kABlock / kASub; sb++) {
+                    tx_fir_block(c_tx_hilbert[0], x.fir_i, bi + sb * kASub);
+                    tx_fir_block(c_tx_hilbert[1], x.fir_q, bq + sb * kASub);
+                }
+                if (m == DDC_MODE_AM)
+                    for (int i = 0; i < kABlock; i++) {
+                        const float i_am = ((bi[i] - bq[i]) + amp) / 2.0f;
+                        const float q_am = ((bq[i] - bi[i]) - amp) / 2.0f;
+                        bi[i] = i_am; bq[i] = q_am;
+                    }
+                break;
+            case DDC_MODE_NFM: case DDC_MODE_WFM:
+                for (int i = 0; i < kABlock; i++) { // ModulateFM
+                    const float a = bi[i];
+                    fb = 0.95f * (fb + a - fa);
+                    fa = a;
+                    facc = f2u_sat((float)facc + fb) % 48000u;
+                    const float sd = (facc / (float)48000) * kPiF * x.fm_index;
+                    bi[i] = amp * sinf(sd);
+                    bq[i] = amp * cosf(sd);
+                }
+                break;
+            default: break;
+            }
+        }
+        if (p.mute && !tune)
+            for (int i = 0; i < kABlock; i++) { bi[i] = bi[i] * 0; bq[i] = bq[i] * 0; }
+        if (m == DDC_MODE_LOOPBACK && !tune) {
+            const float vol = (float)p.volume / 50.0f;
+            for (int i = 0; i < kABlock; i++) {
+                const int32_t v = f2i_sat(bi[i] * vol);
+                if (lp) { lp[2 * (b0 + i)] = v; lp[2 * (b0 + i) + 1] = v; }
+                dst[b0 + i] = 0;
+            }
+        } else
+            for (int i = 0; i < kABlock; i++) {
+                const uint32_t wi = (uint32_t)(uint16_t)(int16_t)f2i_sat(bi[i]);
+                const uint32_t wq = (uint32_t)(uint16_t)(int16_t)f2i_sat(bq[i]);
+                dst[b0 + i] = wi | (wq << 16);
+                if (lp) { lp[2 * (b0 + i)] = 0; lp[2 * (b0 + i) + 1] = 0; }
+            }
+    }
+    s.hpf_i = hpf;
+    s.lpf_i = lpf;
+    x.alc_gain = alc; x.fm_hpf_a = fa; x.fm_hpf_b = fb; x.fm_accum = facc; x.max_amplitude = mxa;
 }
 
 } // namespace ddc

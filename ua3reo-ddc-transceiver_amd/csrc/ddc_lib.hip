@@ -45,10 +45,15 @@ struct ddc_ctx {
     ddc_tx_state tx;
     // 48 kHz audio path / panadapter: per-channel state and FFT work buffers
     ddc::AudioState *d_audio = nullptr;
+    ddc::ZoomState *d_zoom = nullptr;
+    ddc::TxAudioState *d_audio_tx = nullptr;
+    uint32_t fft_zoom_all = 1;         // common zoom factor of all channels (0 = mixed)
     std::vector<uint8_t> audio_ready;  // per channel: ddc_audio_configure seen
+    std::vector<uint8_t> zoom_of;      // per channel: configured FFT zoom
     float2 *d_fft_work = nullptr;      // [ch][n][2] prefiltered SPEC
     float *d_fft_mag = nullptr;        // [ch][frames][256]
-    size_t fft_cap = 0;                // frames per channel the two hold
+    size_t fft_cap = 0;                // frames per channel d_fft_mag holds
+    size_t fft_work_cap = 0;           // float2 per channel d_fft_work holds
     void *d_stage[3] = {nullptr, nullptr, nullptr}; // host-pointer entry points
     size_t stage_cap[3] = {0, 0, 0};
     // optional per-call timing: HIP events on the ctx stream around the front
@@ -122,6 +127,32 @@ int ensure_capacity(ddc_ctx *ctx, uint32_t n_blk)
     ctx->cap_blk = n_blk;
     return 0;
 }
+
+// Zoom-FFT coefficient sets (STM32/Src/fft.c:76-186): 4 biquads {b0,b1,b2,a1,a2}
+// (a's already negated) and a 4-tap decimation FIR per zoom factor 2, 4, 8, 16.
+// The firmware writes them as double literals narrowed to float32.
+const double kZoomBiquad[4][20] = {
+    { 0.228454526413293696, 0.077639329099949764, 0.228454526413293696, 0.635534925142242080, -0.170083307068779194,
+      0.436788292542003964, 0.232307972937606161, 0.436788292542003964, 0.365885230717786780, -0.471769788739400842,
+      0.535974654742658707, 0.557035600464780845, 0.535974654742658707, 0.125740787233286133, -0.754725697183384336,
+      0.501116342273565607, 0.914877831284765408, 0.501116342273565607, 0.013862536615004284, -0.930973052446900984 },
+    { 0.182208761527446556, -0.222492493114674145, 0.182208761527446556, 1.326111070880959810, -0.468036100821178802,
+      0.337123762652097259, -0.366352718812586853, 0.337123762652097259, 1.337053579516321200, -0.644948386007929031,
+      0.336163175380826074, -0.199246162162897811, 0.336163175380826074, 1.354952684569386670, -0.828032873168141115,
+      0.178588201750411041, 0.207271695028067304, 0.178588201750411041, 1.386486967455699220, -0.950935065984588657 },
+    { 0.185643392652478922, -0.332064345389014803, 0.185643392652478922, 1.654637402827731090, -0.693859842743674182,
+      0.327519300813245984, -0.571358085216950418, 0.327519300813245984, 1.715375037176782860, -0.799055553586324407,
+      0.283656142708241688, -0.441088976843048652, 0.283656142708241688, 1.778230635987093860, -0.904453944560528522,
+      0.079685368654848945, -0.011231810140649204, 0.079685368654848945, 1.825046003243238070, -0.973184930412286708 },
+    { 0.194769868656866380, -0.379098413160710079, 0.194769868656866380, 1.824436402073870810, -0.834877726226893380,
+      0.333973874901496770, -0.646106479315673776, 0.333973874901496770, 1.871892825636887640, -0.893734096124207178,
+      0.272903880596429671, -0.513507745397738469, 0.272903880596429671, 1.918161772571113750, -0.950461788366234739,
+      0.053535383722369843, -0.069683422367188122, 0.053535383722369843, 1.948900719896301760, -0.986288064973853129 } };
+const double kZoomFir[4][4] = {
+    { 475.1179397144384210E-6, 0.503905202786044337, 0.503905202786044337, 475.1179397144384210E-6 },
+    { 0.198273254218889416, 0.298085149879260325, 0.298085149879260325, 0.198273254218889416 },
+    { 0.199820836596682871, 0.272777397353925699, 0.272777397353925699, 0.199820836596682871 },
+    { 0.199820836596682871, 0.272777397353925699, 0.272777397353925699, 0.199820836596682871 } };
 
 } // namespace
 
@@ -212,8 +243,15 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
                                       hipMemcpyHostToDevice, ctx->stream));
     ctx->h_phi.assign(nch, 0);
     ctx->audio_ready.assign(nch, 0);
+    ctx->zoom_of.assign(nch, 1);
     CREATE_TRY(hipMalloc(&ctx->d_audio, nch * sizeof(ddc::AudioState)));
     CREATE_TRY(hipMemsetAsync(ctx->d_audio, 0, nch * sizeof(ddc::AudioState), ctx->stream));
+    CREATE_TRY(hipMalloc(&ctx->d_zoom, nch * sizeof(ddc::ZoomState)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_zoom, 0, nch * sizeof(ddc::ZoomState), ctx->stream));
+    CREATE_TRY(hipMalloc(&ctx->d_audio_tx, nch * sizeof(ddc::TxAudioState)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_audio_tx, 0, nch * sizeof(ddc::TxAudioState), ctx->stream));
+    CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_i, sizeof tx_hilbert_i, 0));
+    CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_q, sizeof tx_hilbert_q, sizeof tx_hilbert_i));
     {
         // Hamming window as the firmware evaluates it (fft.c:249-251) and the
         // 512-point twiddles
@@ -244,7 +282,7 @@ void ddc_destroy(ddc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
-                     ctx->d_out, ctx->d_audio, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
+                     ctx->d_out, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
                      ctx->d_stage[2] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -625,13 +663,44 @@ int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p
         st.cw_limit_low = 50;
         memset(st.cw_text, ' ', 15);
     }
+    static ddc::ZoomState zs; // 4 KB: not on the stack of a small-stack caller
+    memset(&zs, 0, sizeof zs);
+    zs.zoom = p->fft_zoom > 1 ? p->fft_zoom : 1;
+    if (zs.zoom > 1) { // FFT_Init, fft.c:188-209
+        int zi;
+        switch (zs.zoom) { case 2: zi = 0; break; case 4: zi = 1; break; case 8: zi = 2; break; case 16: zi = 3; break;
+                           default: return fail(ctx, -EINVAL, "fft_zoom must be 1, 2, 4, 8 or 16"); }
+        for (int i = 0; i < 20; i++) zs.c[i] = (float)kZoomBiquad[zi][i];
+        for (int i = 0; i < 4; i++) zs.fir[i] = (float)kZoomFir[zi][i];
+    }
+    static ddc::TxAudioState ts;
+    memset(&ts, 0, sizeof ts);
+    ts.alc_gain = 1.0f;
+    ts.fm_index = 2.0f; // ModulateFM, audio_processor.c:597-606
+    switch (p->filter_width) {
+    case 5000: ts.fm_index = 2.0f; break; case 6000: ts.fm_index = 3.0f; break; case 7000: ts.fm_index = 4.0f; break;
+    case 8000: ts.fm_index = 5.0f; break; case 9000: ts.fm_index = 6.0f; break; case 9500: ts.fm_index = 7.0f; break;
+    case 10000: ts.fm_index = 8.0f; break; case 15000: ts.fm_index = 9.0f; break; case 0: ts.fm_index = 10.0f; break;
+    default: break; }
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t lo = channel < 0 ? 0 : (size_t)channel;
     const size_t hi = channel < 0 ? ctx->cfg.n_channels : lo + 1;
-    std::vector<ddc::AudioState> all(hi - lo, st);
-    HIP_TRY(ctx, hipMemcpy(ctx->d_audio + lo, all.data(), all.size() * sizeof st, hipMemcpyHostToDevice));
-    for (size_t c = lo; c < hi; c++) ctx->audio_ready[c] = 1;
+    {
+        std::vector<ddc::AudioState> all(hi - lo, st);
+        HIP_TRY(ctx, hipMemcpy(ctx->d_audio + lo, all.data(), all.size() * sizeof st, hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<ddc::ZoomState> all(hi - lo, zs);
+        HIP_TRY(ctx, hipMemcpy(ctx->d_zoom + lo, all.data(), all.size() * sizeof zs, hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<ddc::TxAudioState> all(hi - lo, ts);
+        HIP_TRY(ctx, hipMemcpy(ctx->d_audio_tx + lo, all.data(), all.size() * sizeof ts, hipMemcpyHostToDevice));
+    }
+    for (size_t c = lo; c < hi; c++) { ctx->audio_ready[c] = 1; ctx->zoom_of[c] = (uint8_t)zs.zoom; }
+    ctx->fft_zoom_all = ctx->zoom_of[0];
+    for (uint8_t zv : ctx->zoom_of) if (zv != ctx->zoom_of[0]) ctx->fft_zoom_all = 0;
     return 0;
 }
 
@@ -704,19 +773,24 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
     int rc = audio_all_ready(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    if (fpc > ctx->fft_cap) {
+    // one launch handles one zoom factor: the frame step in the work buffer depends on it
+    if (ctx->fft_zoom_all == 0) return fail(ctx, -EINVAL, "ddc_fft_process needs the same fft_zoom on every channel");
+    const uint32_t M = ctx->fft_zoom_all, zw = 512 / M;
+    const size_t pitch = (512 - zw) + fpc * zw; // float2 per channel
+    if (fpc > ctx->fft_cap || pitch > ctx->fft_work_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_fft_work) (void)hipFree(ctx->d_fft_work);
         if (ctx->d_fft_mag) (void)hipFree(ctx->d_fft_mag);
-        ctx->d_fft_work = nullptr; ctx->d_fft_mag = nullptr; ctx->fft_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_fft_work, nch * fpc * 512 * sizeof(float2)));
+        ctx->d_fft_work = nullptr; ctx->d_fft_mag = nullptr; ctx->fft_cap = 0; ctx->fft_work_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_fft_work, nch * pitch * sizeof(float2)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_fft_mag, nch * fpc * 256 * sizeof(float)));
         ctx->fft_cap = fpc;
+        ctx->fft_work_cap = pitch;
     }
     hipLaunchKernelGGL(ddc::ddc_fft_prefilter, dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, ctx->stream, ctx->d_audio,
-                       (uint32_t)nch, spec_iq, (uint32_t)n_frames, ctx->d_fft_work);
+                       ctx->d_zoom, (uint32_t)nch, spec_iq, (uint32_t)n_frames, ctx->d_fft_work, (uint32_t)pitch);
     hipLaunchKernelGGL(ddc::ddc_fft_frames, dim3((unsigned)(nch * fpc)), dim3(64), 0, ctx->stream, ctx->d_fft_work,
-                       (uint32_t)fpc, ctx->d_fft_mag);
+                       (uint32_t)fpc, (uint32_t)pitch, zw, ctx->d_fft_mag);
     hipLaunchKernelGGL(ddc::ddc_fft_level, dim3((unsigned)nch), dim3(256), 0, ctx->stream, ctx->d_audio, ctx->d_fft_mag,
                        (uint32_t)fpc, bins, rows);
     HIP_TRY(ctx, hipGetLastError());
@@ -743,6 +817,42 @@ int ddc_fft_process(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float
     return 0;
 }
 
+int ddc_audio_tx_process_dev(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, int16_t *iq48k, int32_t *loop_lr)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!mic_lr || !iq48k) return fail(ctx, -EINVAL, "null buffer");
+    if (n_frames % ddc::kABlock) return fail(ctx, -EINVAL, "n_frames must be a multiple of 192");
+    if (n_frames > 0xFFFFFF00u) return fail(ctx, -EINVAL, "n_frames too large");
+    int rc = audio_all_ready(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const uint32_t nch = ctx->cfg.n_channels;
+    hipLaunchKernelGGL(ddc::ddc_audio_tx, dim3((nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, ctx->d_audio_tx,
+                       nch, mic_lr, (uint32_t)n_frames, iq48k, loop_lr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ddc_audio_tx_process(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, int16_t *iq48k, int32_t *loop_lr)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!mic_lr || !iq48k) return fail(ctx, -EINVAL, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t b4 = (size_t)ctx->cfg.n_channels * n_frames * 4;
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, b4)) || (rc = ensure_stage(ctx, 1, b4)) || (rc = ensure_stage(ctx, 2, b4 * 2))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], mic_lr, b4, hipMemcpyHostToDevice, ctx->stream));
+    rc = ddc_audio_tx_process_dev(ctx, (const int16_t *)ctx->d_stage[0], n_frames, (int16_t *)ctx->d_stage[1],
+                                  (int32_t *)ctx->d_stage[2]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(iq48k, ctx->d_stage[1], b4, hipMemcpyDeviceToHost, ctx->stream));
+    if (loop_lr) HIP_TRY(ctx, hipMemcpyAsync(loop_lr, ctx->d_stage[2], b4 * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out)
 {
     int rc = check_channel(ctx, channel);
@@ -759,6 +869,14 @@ int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out)
     out->cw_wpm = st.cw_wpm;
     out->squelched = st.squelched;
     out->blocks = st.blocks;
+    ddc::TxAudioState *ts = nullptr;
+    {
+        static thread_local ddc::TxAudioState tsv;
+        HIP_TRY(ctx, hipMemcpy(&tsv, ctx->d_audio_tx + channel, sizeof tsv, hipMemcpyDeviceToHost));
+        ts = &tsv;
+    }
+    out->alc_gain = ts->alc_gain;
+    out->tx_max_amplitude = ts->max_amplitude;
     memcpy(out->cw_text, st.cw_text, 16);
     return 0;
 }

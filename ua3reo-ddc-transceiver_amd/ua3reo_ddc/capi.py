@@ -101,6 +101,8 @@ def lib():
     L.ddc_fft_process_dev.argtypes = [vp, vp, sz, vp, vp]
     L.ddc_fft_process.argtypes = [vp, vp, sz, vp, vp]
     L.ddc_audio_get_status.argtypes = [vp, i32, vp]
+    L.ddc_audio_tx_process_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.ddc_audio_tx_process.argtypes = [vp, vp, sz, vp, vp]
     L.ddc_synth_adc.argtypes = [u32, u32, sz, vp]
     L.ddc_synth_adc.restype = None
     _lib = L
@@ -122,6 +124,7 @@ class AudioParams(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("agc", C.c_uint8), ("dnr", C.c_uint8), ("notch", C.c_uint8),
                 ("mute", C.c_uint8), ("cw_decoder", C.c_uint8), ("fm_sql_threshold", C.c_uint8),
                 ("volume", C.c_uint8), ("iq_swap", C.c_uint8), ("fft_averaging", C.c_uint8),
+                ("fft_zoom", C.c_uint8), ("rf_power", C.c_uint8), ("tune", C.c_uint8), ("key", C.c_uint8),
                 ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("filter_width", C.c_uint16),
                 ("hpf_pass", C.c_uint16), ("notch_fc", C.c_uint16), ("agc_speed", C.c_uint16),
                 ("rf_gain", C.c_float)]
@@ -130,16 +133,17 @@ class AudioParams(C.Structure):
 class AudioStatus(C.Structure):
     _fields_ = [("smeter_max", C.c_float), ("smeter_min", C.c_float), ("agc_gain", C.c_float),
                 ("fft_max_value", C.c_float), ("cw_wpm", C.c_uint32), ("squelched", C.c_uint32),
-                ("blocks", C.c_uint32), ("cw_text", C.c_char * 16)]
+                ("blocks", C.c_uint32), ("alc_gain", C.c_float), ("tx_max_amplitude", C.c_float),
+                ("cw_text", C.c_char * 16)]
 
 
 def audio_params(mode="USB", agc=1, dnr=0, notch=0, mute=0, cw_decoder=0, fm_sql_threshold=0, volume=50,
                  iq_swap=0, fft_averaging=4, filter_width=2700, hpf_pass=300, notch_fc=1000, agc_speed=3,
-                 rf_gain=50.0):
+                 rf_gain=50.0, fft_zoom=1, rf_power=50, tune=0, key=0):
     """Defaults follow LoadSettings (STM32/Src/settings.c:33-120) where it names one."""
     m = MODES[mode] if isinstance(mode, str) else int(mode)
     return AudioParams(m, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume, iq_swap, fft_averaging,
-                       0, 0, filter_width, hpf_pass, notch_fc, agc_speed, rf_gain)
+                       fft_zoom, rf_power, tune, key, 0, 0, filter_width, hpf_pass, notch_fc, agc_speed, rf_gain)
 
 
 def _np_ptr(a):
@@ -254,6 +258,19 @@ class Ddc:
     def audio_rx_process_dev(self, spec_ptr, voice_ptr, n_frames, audio_ptr):
         self._check(self._L.ddc_audio_rx_process_dev(self._h, spec_ptr, voice_ptr, n_frames, audio_ptr))
 
+    def audio_tx_process(self, mic_lr):
+        """Host path. mic int16 [n_channels][n][2] (L, R) -> (iq int16 [n_channels][n][2],
+        loopback int32 [n_channels][n][2])."""
+        m = np.ascontiguousarray(mic_lr, dtype=np.int16)
+        assert m.ndim == 3 and m.shape[0] == self.n_channels and m.shape[2] == 2
+        iq = np.zeros(m.shape, np.int16)
+        loop = np.zeros(m.shape, np.int32)
+        self._check(self._L.ddc_audio_tx_process(self._h, _np_ptr(m), m.shape[1], _np_ptr(iq), _np_ptr(loop)))
+        return iq, loop
+
+    def audio_tx_process_dev(self, mic_ptr, n_frames, iq_ptr, loop_ptr=None):
+        self._check(self._L.ddc_audio_tx_process_dev(self._h, mic_ptr, n_frames, iq_ptr, loop_ptr))
+
     def fft_process(self, spec_iq):
         """Host path. spec int16 [n_channels][n][2], n % 512 == 0 -> (bins float32
         [n_channels][n/512][256], rows uint16 [n_channels][n/512][256])."""
@@ -273,7 +290,7 @@ class Ddc:
         self._check(self._L.ddc_audio_get_status(self._h, channel, C.byref(st)))
         return {"smeter_max": st.smeter_max, "smeter_min": st.smeter_min, "agc_gain": st.agc_gain,
                 "fft_max_value": st.fft_max_value, "cw_wpm": st.cw_wpm, "squelched": bool(st.squelched),
-                "blocks": st.blocks, "cw_text": bytes(st.cw_text).split(b"\0")[0].decode("ascii", "replace")}
+                "blocks": st.blocks, "alc_gain": st.alc_gain, "tx_max_amplitude": st.tx_max_amplitude, "cw_text": bytes(st.cw_text).split(b"\0")[0].decode("ascii", "replace")}
 
     def sync(self):
         self._check(self._L.ddc_sync(self._h))
