@@ -128,6 +128,27 @@ void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_i
 /* Applies a command-1 payload to a channel: tuning word and RX/TX direction. */
 int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4]);
 
+/* Status frame: command 2 reply of the bus (FPGA/stm32_interface.v:172-205), read
+ * by FPGA_fpgadata_getparam (STM32/Src/fpga.c:222-284): {bit0 ADC_OTR, bit1
+ * DAC_OTR, bits 2-5 keys}, {ADC_MIN[11:8] << 4 | ADC_MAX[11:8]}, ADC_MIN[7:0],
+ * ADC_MAX[7:0], {encoder}.  ADC_MIN / ADC_MAX (:384-397) are the extremes of the
+ * channel's ADC words since the last status read (reset to 2000 / -2000 by the
+ * read); they are gathered by an extra pass over the rows of every
+ * ddc_rx_process* call while ddc_adc_stats_enable is on (off by default).  Keys
+ * and encoder read 0; DAC_OTR cannot rise (see ddc_tx_process). */
+int ddc_adc_stats_enable(ddc_ctx *ctx, int on);
+int ddc_get_status(ddc_ctx *ctx, int32_t channel, uint8_t out[5]);
+void ddc_parse_status(const uint8_t in[5], int *adc_otr, int *dac_otr, int *adc_min, int *adc_max);
+
+/* Whole-ctx state (every channel's NCO phases, tuning words, filter histories,
+ * audio / FFT / TX state) as one host blob, for checkpoint / migration between
+ * GPUs.  The reference keeps this state in FPGA registers and MCU statics and has
+ * no counterpart.  A blob only restores into a ctx with the same channel count;
+ * work queued on the ctx stream is waited for first. */
+size_t ddc_state_size(ddc_ctx *ctx);
+int ddc_state_save(ddc_ctx *ctx, void *buf, size_t size);
+int ddc_state_restore(ddc_ctx *ctx, const void *buf, size_t size);
+
 /* ---- 48 kHz audio path and panadapter (the STM32 half of the reference) ------
  *
  * Demodulator modes, numbered as STM32/Src/trx_manager.h:11-22. */

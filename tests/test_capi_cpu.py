@@ -73,3 +73,13 @@ def test_synthetic_signal_definition(ddc):
     assert np.max(np.abs(x - np.round(tone))) <= 64
     assert np.array_equal(x, ddc.synth_adc(3, 4096))
     assert not np.array_equal(x, ddc.synth_adc(4, 4096))
+
+
+def test_parse_status_frame():
+    import ua3reo_ddc
+    # min = -1234 (0xB2E), max = 1999 (0x7CF), ADC over-range set
+    frame = bytes([0x01, (0xB << 4) | 0x7, 0x2E, 0xCF, 0])
+    assert ua3reo_ddc.parse_status(frame) == (1, 0, -1234, 1999)
+    # the reset value of ADC_MAX (-2000) reads back unsigned, as the firmware takes it
+    frame = bytes([0x02, (0x7 << 4) | 0x8, 0xD0, 0x30, 0])
+    assert ua3reo_ddc.parse_status(frame) == (0, 1, 2000, 0x830)

@@ -181,3 +181,54 @@ def test_device_pointer_path_and_large_batch(ddc, orc):
         os_, ov_ = orc.RxChain(phis[c]).run(x)
         assert np.array_equal(spec[c].cpu().numpy(), os_)
         assert np.array_equal(voice[c].cpu().numpy(), ov_)
+
+
+def test_status_frame_adc_minmax(ddc, orc):
+    samples = 4096
+    rng = np.random.default_rng(61)
+    adc = rng.integers(-900, 901, size=(3, samples)).astype(np.int16)
+    adc[1, 1234] = 2047
+    adc[2, 77] = -2048
+    rows = np.stack([ddc.pack_adc12(a) for a in adc])
+    d = ddc.Ddc(3)
+    d.tune_many([1000, 2000, 3000])
+    # disabled: registers keep their reset values
+    d.rx_process(rows, samples)
+    assert ddc.parse_status(d.get_status(0)) == (0, 0, 2000, (-2000) & 0xFFF)
+    d.adc_stats_enable(True)
+    d.rx_process(rows, samples)
+    d.rx_process(rows[:, :1536], 1024)  # accumulates over calls until read
+    for c in range(3):
+        otr, dac, lo, hi = ddc.parse_status(d.get_status(c))
+        assert (lo, hi) == (int(adc[c].min()), int(adc[c].max()) & 0xFFF)
+        assert otr == (1 if c else 0) and dac == 0
+    # the read reset them
+    assert ddc.parse_status(d.get_status(1)) == (0, 0, 2000, (-2000) & 0xFFF)
+
+
+def test_state_save_restore_resumes_bit_exact(ddc, orc):
+    samples = 1024 * 6
+    rng = np.random.default_rng(62)
+    adc = rng.integers(-2048, 2048, size=(2, 2 * samples)).astype(np.int16)
+    rows_a = np.stack([ddc.pack_adc12(a[:samples]) for a in adc])
+    rows_b = np.stack([ddc.pack_adc12(a[samples:]) for a in adc])
+    phis = [605867, 31337]
+    d = ddc.Ddc(2)
+    d.tune_many(phis)
+    d.audio_configure(ddc.audio_params(mode="USB"))
+    d.rx_process(rows_a, samples)
+    blob = d.state_save()
+    s1, v1 = d.rx_process(rows_b, samples)
+    e = ddc.Ddc(2)                      # a fresh ctx picks the stream up mid-way
+    e.state_restore(blob)
+    s2, v2 = e.rx_process(rows_b, samples)
+    assert np.array_equal(s1, s2) and np.array_equal(v1, v2)
+    for c in range(2):
+        ws, wv = orc.RxChain(phis[c]).run(adc[c])
+        assert np.array_equal(s2[c], ws[samples // 1024:]) and np.array_equal(v2[c], wv[samples // 1024:])
+    # audio state travels too (no configure on e)
+    a1 = d.audio_rx_process(np.tile(s1, (1, 32, 1)), np.tile(v1, (1, 32, 1)))
+    a2 = e.audio_rx_process(np.tile(s2, (1, 32, 1)), np.tile(v2, (1, 32, 1)))
+    assert np.array_equal(a1, a2)
+    with pytest.raises(ddc.DdcError):
+        ddc.Ddc(3).state_restore(blob)

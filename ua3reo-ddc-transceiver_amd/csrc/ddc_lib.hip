@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,9 @@ struct ddc_ctx {
     int16_t *d_out = nullptr;
     size_t out_cap = 0;
     std::vector<uint32_t> h_phi;
+    // ADC_MIN / ADC_MAX registers of the status frame, gathered only when enabled
+    bool adc_stats = false;
+    int *d_adc_min = nullptr, *d_adc_max = nullptr;
     ddc_tx_state tx;
     // 48 kHz audio path / panadapter: per-channel state and FFT work buffers
     ddc::AudioState *d_audio = nullptr;
@@ -242,6 +246,14 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     ctx->h_phi.assign(nch, 0);
+    {
+        // power-on values of the registers (FPGA/stm32_interface.v:385-388)
+        std::vector<int> lo(nch, 2000), hi(nch, -2000);
+        CREATE_TRY(hipMalloc(&ctx->d_adc_min, nch * 4));
+        CREATE_TRY(hipMalloc(&ctx->d_adc_max, nch * 4));
+        CREATE_TRY(hipMemcpy(ctx->d_adc_min, lo.data(), nch * 4, hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(ctx->d_adc_max, hi.data(), nch * 4, hipMemcpyHostToDevice));
+    }
     ctx->audio_ready.assign(nch, 0);
     ctx->zoom_of.assign(nch, 1);
     CREATE_TRY(hipMalloc(&ctx->d_audio, nch * sizeof(ddc::AudioState)));
@@ -282,7 +294,7 @@ void ddc_destroy(ddc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
-                     ctx->d_out, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
+                     ctx->d_out, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
                      ctx->d_stage[2] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -435,6 +447,11 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
                                                  ctx->d_cic, ctx->d_comp, ctx->d_acc, ctx->d_phi, n_blk,
                                                  (uint32_t)samples);
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
+    if (ctx->adc_stats) {
+        const uint32_t pieces = (uint32_t)(samples / 32);
+        const uint32_t gx = std::min<uint32_t>((pieces + 255) / 256, std::max<uint32_t>(1, 4096 / nch));
+        ddc::ddc_adc_minmax<<<dim3(gx, nch), 256, 0, st>>>(adc12, row_bytes, pieces, ctx->d_adc_min, ctx->d_adc_max);
+    }
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_blk = n_blk;
     return 0;
@@ -878,6 +895,131 @@ int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out)
     out->alc_gain = ts->alc_gain;
     out->tx_max_amplitude = ts->max_amplitude;
     memcpy(out->cw_text, st.cw_text, 16);
+    return 0;
+}
+
+/* ---- status frame and state blob ----------------------------------------------- */
+
+int ddc_adc_stats_enable(ddc_ctx *ctx, int on)
+{
+    if (!ctx) return -EINVAL;
+    ctx->adc_stats = on != 0;
+    return 0;
+}
+
+int ddc_get_status(ddc_ctx *ctx, int32_t channel, uint8_t out[5])
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0 || !out) return fail(ctx, -EINVAL, "ddc_get_status needs one channel and an output");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int lo = 0, hi = 0;
+    HIP_TRY(ctx, hipMemcpy(&lo, ctx->d_adc_min + channel, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&hi, ctx->d_adc_max + channel, 4, hipMemcpyDeviceToHost));
+    // The ADC's over-range pin is not part of the sample stream; full-scale codes stand in for it.
+    const int otr = ctx->adc_stats && (hi >= 2047 || lo <= -2048);
+    out[0] = (uint8_t)otr;                                   // bit1 DAC_OTR can never rise, bits 2-5: front-panel keys
+    out[1] = (uint8_t)((((unsigned)lo >> 8) & 0xF) << 4 | (((unsigned)hi >> 8) & 0xF));
+    out[2] = (uint8_t)(lo & 0xFF);
+    out[3] = (uint8_t)(hi & 0xFF);
+    out[4] = 0;                                              // encoder
+    const int rlo = 2000, rhi = -2000;                       // ADC_MINMAX_RESET
+    HIP_TRY(ctx, hipMemcpy(ctx->d_adc_min + channel, &rlo, 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_adc_max + channel, &rhi, 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+void ddc_parse_status(const uint8_t in[5], int *adc_otr, int *dac_otr, int *adc_min, int *adc_max)
+{
+    if (adc_otr) *adc_otr = in[0] & 1;
+    if (dac_otr) *dac_otr = (in[0] >> 1) & 1;
+    // FPGA_fpgadata_getparam (fpga.c:222-284) sign-extends the minimum
+    // (<< 4 then / 16 on an int16) and takes the maximum as an unsigned 12-bit value
+    int lo = ((in[1] >> 4) << 8) | in[2];
+    const int hi = ((in[1] & 0xF) << 8) | in[3];
+    if (lo & 0x800) lo -= 0x1000;
+    if (adc_min) *adc_min = lo;
+    if (adc_max) *adc_max = hi;
+}
+
+extern "C++" {
+namespace {
+struct StateSeg { void *dev; size_t bytes; };
+struct StateHeader { uint32_t magic, version, n_channels, n_seg; uint64_t total; };
+constexpr uint32_t kStateMagic = 0x43444455u; // "UDDC"
+
+std::vector<StateSeg> state_segments(ddc_ctx *ctx)
+{
+    const size_t n = ctx->cfg.n_channels;
+    return {
+        { ctx->d_acc, n * 4 }, { ctx->d_phi, n * 4 }, { ctx->d_carry[ctx->carry_sel], n * 24 },
+        { ctx->d_hist_mom, n * ddc::kMomHist * 10 * sizeof(unsigned long long) },
+        { ctx->d_hist_cic, n * ddc::kCicHist * 4 }, { ctx->d_hist_comp, n * ddc::kCompHist * 4 },
+        { ctx->tx.d_acc, n * 4 }, { ctx->tx.d_hist_x, n * ddc::kTxXHist * 4 }, { ctx->tx.d_hist_y, n * ddc::kTxYHist * 4 },
+        { ctx->d_adc_min, n * 4 }, { ctx->d_adc_max, n * 4 },
+        { ctx->d_audio, n * sizeof(ddc::AudioState) }, { ctx->d_zoom, n * sizeof(ddc::ZoomState) },
+        { ctx->d_audio_tx, n * sizeof(ddc::TxAudioState) },
+    };
+}
+} // namespace
+} // extern "C++"
+
+size_t ddc_state_size(ddc_ctx *ctx)
+{
+    if (!ctx) return 0;
+    size_t t = sizeof(StateHeader) + ctx->cfg.n_channels * 2; // + audio_ready, zoom_of
+    for (const StateSeg &g : state_segments(ctx)) t += g.bytes;
+    return t;
+}
+
+int ddc_state_save(ddc_ctx *ctx, void *buf, size_t size)
+{
+    if (!ctx || !buf) return -EINVAL;
+    const size_t need = ddc_state_size(ctx);
+    if (size < need) return fail(ctx, -ENOSPC, "state buffer too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t *p = static_cast<uint8_t *>(buf);
+    const auto segs = state_segments(ctx);
+    StateHeader h = { kStateMagic, 1, ctx->cfg.n_channels, (uint32_t)segs.size(), need };
+    memcpy(p, &h, sizeof h);
+    p += sizeof h;
+    for (const StateSeg &g : segs) {
+        HIP_TRY(ctx, hipMemcpy(p, g.dev, g.bytes, hipMemcpyDeviceToHost));
+        p += g.bytes;
+    }
+    memcpy(p, ctx->audio_ready.data(), ctx->cfg.n_channels);
+    memcpy(p + ctx->cfg.n_channels, ctx->zoom_of.data(), ctx->cfg.n_channels);
+    return 0;
+}
+
+int ddc_state_restore(ddc_ctx *ctx, const void *buf, size_t size)
+{
+    if (!ctx || !buf) return -EINVAL;
+    const size_t need = ddc_state_size(ctx);
+    StateHeader h;
+    if (size < sizeof h) return fail(ctx, -EINVAL, "state blob truncated");
+    memcpy(&h, buf, sizeof h);
+    const auto segs = state_segments(ctx);
+    if (h.magic != kStateMagic || h.version != 1 || h.n_channels != ctx->cfg.n_channels || h.n_seg != segs.size() ||
+        h.total != need || size < need)
+        return fail(ctx, -EINVAL, "state blob does not match this ctx (magic / version / channel count / size)");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint8_t *p = static_cast<const uint8_t *>(buf) + sizeof h;
+    for (const StateSeg &g : segs) {
+        HIP_TRY(ctx, hipMemcpy(g.dev, p, g.bytes, hipMemcpyHostToDevice));
+        p += g.bytes;
+    }
+    memcpy(ctx->audio_ready.data(), p, ctx->cfg.n_channels);
+    memcpy(ctx->zoom_of.data(), p + ctx->cfg.n_channels, ctx->cfg.n_channels);
+    ctx->fft_zoom_all = ctx->zoom_of[0];
+    for (uint8_t zv : ctx->zoom_of) if (zv != ctx->zoom_of[0]) ctx->fft_zoom_all = 0;
+    // the host mirror of the tuning words
+    std::vector<uint32_t> phi(ctx->cfg.n_channels);
+    HIP_TRY(ctx, hipMemcpy(phi.data(), ctx->d_phi, phi.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < phi.size(); c++) ctx->h_phi[c] = phi[c] >> 10;
     return 0;
 }
 

@@ -409,6 +409,38 @@ __global__ void ddc_rx_cic_combine(const unsigned long long *__restrict__ mom, u
     o[1] = (int16_t)((long long)(acc[1] << 4) >> 48);
 }
 
+/*
+ * Optional pass: running minimum / maximum of the ADC words of every channel,
+ * the ADC_MIN / ADC_MAX registers of FPGA/stm32_interface.v:384-397 that the
+ * status frame reports.  grid (x = slices of a row, y = channel); every thread
+ * walks 48-byte pieces (32 samples) of its channel's row.
+ */
+__global__ __launch_bounds__(256) void ddc_adc_minmax(const uint8_t *__restrict__ adc, size_t row_bytes,
+                                                      uint32_t pieces, int *__restrict__ mn, int *__restrict__ mx)
+{
+    __shared__ int s_mn, s_mx;
+    if (threadIdx.x == 0) { s_mn = 4095; s_mx = -4096; }
+    __syncthreads();
+    const uint32_t ch = blockIdx.y;
+    const uint4 *row = reinterpret_cast<const uint4 *>(adc + (size_t)ch * row_bytes);
+    int lo = 4095, hi = -4096;
+    for (uint32_t pc = blockIdx.x * blockDim.x + threadIdx.x; pc < pieces; pc += gridDim.x * blockDim.x) {
+        const uint4 v0 = row[3 * (size_t)pc], v1 = row[3 * (size_t)pc + 1], v2 = row[3 * (size_t)pc + 2];
+        const uint32_t d[12] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w };
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            int a[8];
+            unpack8(d[3 * g], d[3 * g + 1], d[3 * g + 2], a);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { lo = min(lo, a[k]); hi = max(hi, a[k]); }
+        }
+    }
+    atomicMin(&s_mn, lo);
+    atomicMax(&s_mx, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicMin(&mn[ch], s_mn); atomicMax(&mx[ch], s_mx); }
+}
+
 // convergent rounding as the generated HDL codes it, on the low `bits` bits
 __device__ __forceinline__ int cround32(uint32_t v, int s, int bits)
 {

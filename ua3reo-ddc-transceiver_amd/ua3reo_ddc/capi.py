@@ -95,6 +95,14 @@ def lib():
     L.ddc_pack_adc12.restype = None
     L.ddc_unpack_adc12.argtypes = [vp, sz, vp]
     L.ddc_unpack_adc12.restype = None
+    L.ddc_adc_stats_enable.argtypes = [vp, C.c_int]
+    L.ddc_get_status.argtypes = [vp, i32, vp]
+    L.ddc_parse_status.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ddc_parse_status.restype = None
+    L.ddc_state_size.argtypes = [vp]
+    L.ddc_state_size.restype = sz
+    L.ddc_state_save.argtypes = [vp, vp, sz]
+    L.ddc_state_restore.argtypes = [vp, vp, sz]
     L.ddc_audio_configure.argtypes = [vp, i32, vp]
     L.ddc_audio_rx_process_dev.argtypes = [vp, vp, vp, sz, vp]
     L.ddc_audio_rx_process.argtypes = [vp, vp, vp, sz, vp]
@@ -292,6 +300,25 @@ class Ddc:
                 "fft_max_value": st.fft_max_value, "cw_wpm": st.cw_wpm, "squelched": bool(st.squelched),
                 "blocks": st.blocks, "alc_gain": st.alc_gain, "tx_max_amplitude": st.tx_max_amplitude, "cw_text": bytes(st.cw_text).split(b"\0")[0].decode("ascii", "replace")}
 
+    def adc_stats_enable(self, on=True):
+        self._check(self._L.ddc_adc_stats_enable(self._h, 1 if on else 0))
+
+    def get_status(self, channel):
+        """The 5-byte command-2 reply of the bus for one channel (resets ADC min/max)."""
+        out = np.zeros(5, np.uint8)
+        self._check(self._L.ddc_get_status(self._h, channel, _np_ptr(out)))
+        return out
+
+    def state_save(self):
+        n = self._L.ddc_state_size(self._h)
+        buf = np.zeros(n, np.uint8)
+        self._check(self._L.ddc_state_save(self._h, _np_ptr(buf), n))
+        return buf
+
+    def state_restore(self, blob):
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._check(self._L.ddc_state_restore(self._h, _np_ptr(b), b.size))
+
     def sync(self):
         self._check(self._L.ddc_sync(self._h))
 
@@ -352,6 +379,14 @@ def unpack_tx_frames(frames):
     out = np.zeros((n, 2), np.int16)
     lib().ddc_unpack_tx_frames(_np_ptr(f), n, _np_ptr(out))
     return out
+
+
+def parse_status(b):
+    """(adc_otr, dac_otr, adc_min, adc_max) of a 5-byte status frame."""
+    buf = np.frombuffer(bytes(b), dtype=np.uint8).copy()
+    a, d, lo, hi = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    lib().ddc_parse_status(_np_ptr(buf), C.byref(a), C.byref(d), C.byref(lo), C.byref(hi))
+    return a.value, d.value, lo.value, hi.value
 
 
 def parse_params(b):
