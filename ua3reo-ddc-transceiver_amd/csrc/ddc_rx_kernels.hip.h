@@ -162,6 +162,16 @@ struct Cascade {
         t30 += mu[3]; t31 += t30;
         t40 += mu[4];
     }
+    // Adds what a step with local moments mu, taken before the sixteen steps this
+    // cascade has run, would have left behind: C(16 + q, q) * mu[i] in T[i][q].
+    __device__ __forceinline__ void inject_first(const int (&mu)[5])
+    {
+        t00 += mu[0]; t01 += 17 * mu[0]; t02 += 153 * mu[0]; t03 += 969 * mu[0]; t04 += 4845ll * mu[0];
+        t10 += mu[1]; t11 += 17 * mu[1]; t12 += 153ll * mu[1]; t13 += 969ll * mu[1];
+        t20 += mu[2]; t21 += 17ll * mu[2]; t22 += 153ll * mu[2];
+        t30 += mu[3]; t31 += 17ll * mu[3];
+        t40 += mu[4];
+    }
     // B[e] = sum_{i<=e} sum_{q<=e-i} GAM[e-i][q] * T[i][q]   (mod 2^64)
     __device__ __forceinline__ void moments(unsigned long long (&B)[5]) const
     {
@@ -181,6 +191,14 @@ struct Cascade {
     }
 };
 
+// v_dot2_i32_i16 with a zero addend: starts an accumulator without a move to clear it
+__device__ __forceinline__ int dot2_first(unsigned a, unsigned w)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+
 template <int P>
 __device__ __forceinline__ void pair_acc(unsigned pk_i, unsigned pk_q, int (&mi)[5], int (&mq)[5])
 {
@@ -189,6 +207,14 @@ __device__ __forceinline__ void pair_acc(unsigned pk_i, unsigned pk_q, int (&mi)
     constexpr unsigned w2 = pack_w(psi_w(2, 2 * P), psi_w(2, 2 * P + 1));
     constexpr unsigned w3 = pack_w(psi_w(3, 2 * P), psi_w(3, 2 * P + 1));
     constexpr unsigned w4 = pack_w(psi_w(4, 2 * P), psi_w(4, 2 * P + 1));
+    if (P == 0) { // first pair of a chunk
+        mi[0] = dot2_first(pk_i, w0); mq[0] = dot2_first(pk_q, w0);
+        mi[1] = dot2_first(pk_i, w1); mq[1] = dot2_first(pk_q, w1);
+        mi[2] = dot2_first(pk_i, w2); mq[2] = dot2_first(pk_q, w2);
+        mi[3] = dot2_first(pk_i, w3); mq[3] = dot2_first(pk_q, w3);
+        mi[4] = dot2_first(pk_i, w4); mq[4] = dot2_first(pk_q, w4);
+        return;
+    }
     mi[0] = dot2(pk_i, w0, mi[0]); mq[0] = dot2(pk_q, w0, mq[0]);
     mi[1] = dot2(pk_i, w1, mi[1]); mq[1] = dot2(pk_q, w1, mq[1]);
     mi[2] = dot2(pk_i, w2, mi[2]); mq[2] = dot2(pk_q, w2, mq[2]);
@@ -250,15 +276,25 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
 /*
  * Kernel 1.  One thread owns one natural block of 512 samples of one channel
  * (global block id g = channel * n_blk + block); a workgroup owns 256
- * consecutive ids.  The ADC bytes of the workgroup are staged through LDS in
- * 16 slices of 256 x 48 B so that HBM is read in whole coalesced 16-byte lanes
- * while every thread walks its own 768-byte run.
+ * consecutive ids.  A block is 768 bytes = six 128-byte lines.  The workgroup
+ * stages one whole line per thread at a time through LDS (8 lanes fetch the
+ * eight 16-byte pieces of one line, so HBM / L2 see every line exactly once and
+ * as one full-line request), and every thread walks its 48-byte chunks across
+ * the lines; the 32 / 16 bytes of a line that belong to the next chunk wait in
+ * registers while the next line lands.  The load of the next line is issued
+ * before the last chunk of the current one is computed, which hides its latency.
+ *
+ * LDS line buffer: row r (= thread r) holds its line at r * 128, piece p in slot
+ * p ^ swz(r); the swizzle makes the 16-byte reads of 16 consecutive threads hit
+ * 16 different bank groups.
  *
  *   mom  [channel][kMomHist + n_blk][2][5] u64 : window moments, I then Q;
  *        this kernel writes records kMomHist + block
  *   carry_in / carry_out [channel][6] : packed mixer outputs of the last six
  *        samples of the previous / this call (I pairs 13..15, Q pairs 13..15)
  */
+__device__ __forceinline__ uint32_t line_swz(uint32_t row) { return ((row >> 1) & 3u) ^ (((row >> 3) & 1u) << 2); }
+
 __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t total_blocks,
     const uint32_t *__restrict__ acc0, const uint32_t *__restrict__ phi32v,
@@ -266,21 +302,32 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     unsigned long long *__restrict__ mom, const uint2 *__restrict__ nco_tab)
 {
     __shared__ uint2 tab[2048];
-    __shared__ uint4 stage[2][3 * kFrontThreads];
+    __shared__ uint4 lines[8 * kFrontThreads];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t g0 = blockIdx.x * kFrontThreads;
     for (uint32_t i = tid; i < 2048; i += kFrontThreads) tab[i] = nco_tab[i];
 
-    // staging sources: 16-byte piece q = tid + 256 j belongs to thread q / 3
-    const uint8_t *src[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const uint32_t q = tid + kFrontThreads * j;
-        uint32_t go = g0 + q / 3;
+    // staging sources: load j of a wave covers rows wave_base + 8 j .. + 7, lane l
+    // fetching for row 8 j + (l >> 3) the piece that lives in slot l & 7
+    const uint32_t lane = tid & 63u, wave_base = tid & ~63u;
+    const uint8_t *src[8];
+    {
+        uint32_t go = g0 + wave_base + (lane >> 3);
         go = go < total_blocks ? go : total_blocks - 1;
-        const uint32_t cho = go / n_blk, bo = go - cho * n_blk;
-        src[j] = adc + (size_t)cho * row_bytes + (size_t)bo * kBlkBytes + (q % 3) * 16;
+        uint32_t cho = go / n_blk, bo = go - cho * n_blk;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t row = wave_base + 8u * j + (lane >> 3);
+            const uint32_t piece = (lane & 7u) ^ line_swz(row);
+            src[j] = adc + (size_t)cho * row_bytes + (size_t)bo * kBlkBytes + piece * 16u;
+            // eight blocks on, unless that runs past the last block of the launch
+            if (go + 8u < total_blocks) {
+                go += 8u;
+                bo += 8u;
+                while (bo >= n_blk) { bo -= n_blk; cho++; }
+            }
+        }
     }
 
     const uint32_t g = g0 + tid;
@@ -290,9 +337,8 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     const uint32_t phi32 = phi32v[ch];
     uint32_t acc32 = acc0[ch] + (b * (uint32_t)kBlk) * phi32;
 
-    const uint32_t wave_base = tid & ~63u;
 #pragma unroll
-    for (int j = 0; j < 3; j++) lds_dma16(src[j], &stage[0][wave_base + kFrontThreads * j]);
+    for (int j = 0; j < 8; j++) lds_dma16(src[j], &lines[(wave_base + 8 * j) * 8]);
 
     Cascade ci, cq;
     ci.clear();
@@ -300,53 +346,42 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
 
     __syncthreads(); // tab is ready
 
-    // step 0: the five samples before this block open the window
-    {
-        unsigned pki[3], pkq[3];
-        if (b == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                pki[k] = carry_in[ch * 6 + k];
-                pkq[k] = carry_in[ch * 6 + 3 + k];
-            }
-        } else {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(
-                adc + (size_t)ch * row_bytes + (size_t)b * kBlkBytes - 12);
-            int a[8];
-            unpack8(p[0], p[1], p[2], a);
-            uint32_t ph = acc32 - 6u * phi32;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                int xi0, xq0, xi1, xq1;
-                nco_mix(tab, ph, a[2 + 2 * k], xi0, xq0);
-                ph += phi32;
-                nco_mix(tab, ph, a[3 + 2 * k], xi1, xq1);
-                ph += phi32;
-                pki[k] = pack16(xi0, xi1);
-                pkq[k] = pack16(xq0, xq1);
-            }
-        }
-        int mi[5] = {0, 0, 0, 0, 0}, mq[5] = {0, 0, 0, 0, 0};
-        tail5_acc<1>(pki, mi);
-        tail5_acc<1>(pkq, mq);
-        ci.step(mi);
-        cq.step(mq);
-    }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // own row in the line buffer: piece p sits at mine ^ (p << 4) (byte address)
+    const uint32_t mine = tid * 128u + (line_swz(tid) << 4);
+    const char *lbase = reinterpret_cast<const char *>(lines);
+#define DDC_PIECE(p) (*reinterpret_cast<const uint4 *>(lbase + (mine ^ ((p) << 4))))
 
     unsigned last_i[3] = {0, 0, 0}, last_q[3] = {0, 0, 0};
+    uint4 left0 = make_uint4(0, 0, 0, 0), left1 = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
     for (int a = 0; a < kChunksPerBlk; a++) {
-        if (a + 1 < kChunksPerBlk) {
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                lds_dma16(src[j] + (a + 1) * kChunkBytes, &stage[(a + 1) & 1][wave_base + kFrontThreads * j]);
+        const int c = a & 7; // chunk within the half block of three lines
+        if (c == 0 || c == 2 || c == 5) { // first chunk that needs a new line
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        const uint4 *mine = &stage[a & 1][3 * tid];
-        const uint4 v0 = mine[0], v1 = mine[1], v2 = mine[2];
-        int mi[5] = {0, 0, 0, 0, 0}, mq[5] = {0, 0, 0, 0, 0};
+        uint4 v0, v1, v2;
+        switch (c) {
+        case 0: v0 = DDC_PIECE(0); v1 = DDC_PIECE(1); v2 = DDC_PIECE(2); break;
+        case 1: v0 = DDC_PIECE(3); v1 = DDC_PIECE(4); v2 = DDC_PIECE(5); left0 = DDC_PIECE(6); left1 = DDC_PIECE(7); break;
+        case 2: v0 = left0; v1 = left1; v2 = DDC_PIECE(0); break;
+        case 3: v0 = DDC_PIECE(1); v1 = DDC_PIECE(2); v2 = DDC_PIECE(3); break;
+        case 4: v0 = DDC_PIECE(4); v1 = DDC_PIECE(5); v2 = DDC_PIECE(6); left0 = DDC_PIECE(7); break;
+        case 5: v0 = left0; v1 = DDC_PIECE(0); v2 = DDC_PIECE(1); break;
+        case 6: v0 = DDC_PIECE(2); v1 = DDC_PIECE(3); v2 = DDC_PIECE(4); break;
+        default: v0 = DDC_PIECE(5); v1 = DDC_PIECE(6); v2 = DDC_PIECE(7); break;
+        }
+        if (c == 1 || c == 4 || c == 7) { // last chunk of a line: free the buffer, start the next line
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (a + 1 < kChunksPerBlk) {
+                const int next_line = (a >> 3) * 3 + (c == 1 ? 1 : c == 4 ? 2 : 3);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    lds_dma16(src[j] + next_line * 128, &lines[(wave_base + 8 * j) * 8]);
+            }
+        }
+        int mi[5], mq[5];
         group8<0>(tab, v0.x, v0.y, v0.z, acc32, phi32, mi, mq, last_i, last_q);
         group8<1>(tab, v0.w, v1.x, v1.y, acc32, phi32, mi, mq, last_i, last_q);
         group8<2>(tab, v1.z, v1.w, v2.x, acc32, phi32, mi, mq, last_i, last_q);
@@ -357,10 +392,57 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
         }
         ci.step(mi);
         cq.step(mq);
-        if (a + 1 < kChunksPerBlk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+    }
+#undef DDC_PIECE
+
+    // The five samples before this block open its window.  They are the last
+    // samples of the block to the left: its thread hands their mixer outputs over
+    // through LDS (the line buffer is free now); only the first thread of the
+    // workgroup has to fetch and mix them itself, and the first block of a call
+    // takes them from the previous call.
+    {
+        uint32_t *xch = reinterpret_cast<uint32_t *>(lines);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            xch[k * kFrontThreads + tid] = last_i[k];
+            xch[(3 + k) * kFrontThreads + tid] = last_q[k];
         }
+        __syncthreads();
+        unsigned pki[3], pkq[3];
+        if (b == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pki[k] = carry_in[ch * 6 + k];
+                pkq[k] = carry_in[ch * 6 + 3 + k];
+            }
+        } else if (tid == 0) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(
+                adc + (size_t)ch * row_bytes + (size_t)b * kBlkBytes - 12);
+            int a[8];
+            unpack8(p[0], p[1], p[2], a);
+            uint32_t ph = acc0[ch] + (b * (uint32_t)kBlk - 6u) * phi32;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                int xi0, xq0, xi1, xq1;
+                nco_mix(tab, ph, a[2 + 2 * k], xi0, xq0);
+                ph += phi32;
+                nco_mix(tab, ph, a[3 + 2 * k], xi1, xq1);
+                ph += phi32;
+                pki[k] = pack16(xi0, xi1);
+                pkq[k] = pack16(xq0, xq1);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pki[k] = xch[k * kFrontThreads + tid - 1];
+                pkq[k] = xch[(3 + k) * kFrontThreads + tid - 1];
+            }
+        }
+        int mi[5] = {0, 0, 0, 0, 0}, mq[5] = {0, 0, 0, 0, 0};
+        tail5_acc<1>(pki, mi);
+        tail5_acc<1>(pkq, mq);
+        ci.inject_first(mi);
+        cq.inject_first(mq);
     }
 
     if (!active) return;
