@@ -191,6 +191,13 @@ typedef struct ddc_audio_status {
  * Must be called before the first audio / FFT call.  -EINVAL when filter_width or
  * hpf_pass name no table of the firmware. */
 int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p);
+/* Changes the settings that select no filter (agc, dnr, notch on/off, mute,
+ * cw_decoder, fm_sql_threshold, volume, iq_swap, fft_averaging, rf_power, tune, key,
+ * agc_speed, rf_gain) and keeps all running state, as the firmware does when it
+ * reads TRX.* on the next block.  mode, filter_width, hpf_pass, notch_fc and
+ * fft_zoom must equal the configured ones (-EINVAL otherwise: use
+ * ddc_audio_configure). */
+int ddc_audio_update(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p);
 /* processRxAudio (audio_processor.c:275-435) for all channels.  spec_iq/voice_iq:
  * [n_channels][n_frames][2] int16 as ddc_rx_process_dev writes them; n_frames a
  * multiple of 192 (the firmware's half-buffer); audio_lr: [n_channels][n_frames][2]
@@ -221,6 +228,14 @@ int ddc_fft_process(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, float
  * (IIR_HPF_I, IIR_LPF_I). */
 int ddc_audio_tx_process_dev(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, int16_t *iq48k, int32_t *loop_lr);
 int ddc_audio_tx_process(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, int16_t *iq48k, int32_t *loop_lr);
+/* One stage of the RX audio path on one channel's state, for hosts that still call
+ * the firmware's fine-grained functions: dc_filter (audio_filters.h:51, slot in
+ * arg), DoAGC (agc.h:10, n = 192), processNoiseReduction (noise_reduction.h:16,
+ * n = 64, in place), CWDecoder_Process (cw_decoder.h:21, n = 192, arg = the
+ * millisecond clock HAL_GetTick() would return).  buf is host memory, processed
+ * in place; the call waits for the result. */
+enum ddc_audio_stage_id { DDC_STAGE_DC = 0, DDC_STAGE_AGC = 1, DDC_STAGE_DNR = 2, DDC_STAGE_CW = 3 };
+int ddc_audio_stage(ddc_ctx *ctx, int32_t channel, int stage, int arg, float *buf, int n);
 /* S-meter extremes, AGC / ALC gain, CW decoder text (waits for the ctx stream). */
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
 

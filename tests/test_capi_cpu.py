@@ -83,3 +83,32 @@ def test_parse_status_frame():
     # the reset value of ADC_MAX (-2000) reads back unsigned, as the firmware takes it
     frame = bytes([0x02, (0x7 << 4) | 0x8, 0xD0, 0x30, 0])
     assert ua3reo_ddc.parse_status(frame) == (0, 1, 2000, 0x830)
+
+
+def legacy_symbols():
+    """Functions and extern objects ua3reo_legacy.h declares."""
+    txt = open(os.path.join(ROOT, "include", "ua3reo_legacy.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"typedef struct \{.*?\} VFO;", "", txt, flags=re.S)
+    names = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt))
+    names -= {"defined", "FPGA_AUDIO_BUFFER_SIZE", "FPGA_AUDIO_BUFFER_HALF_SIZE"}
+    for decl in re.findall(r"extern\s+(?!\"C\")[^;{]*;", txt):
+        for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*(,|;)", decl):
+            names.add(m.group(1))
+    names.add("TRX")
+    return sorted(n for n in names if not n.isupper() or n == "TRX")
+
+
+def test_library_exports_the_firmware_interface(ddc):
+    L = ddc.lib()
+    names = legacy_symbols()
+    for must in ("processRxAudio", "processTxAudio", "initAudioProcessor", "FFT_Init", "FFT_doFFT", "InitAudioFilters",
+                 "ReinitAudioFilters", "InitNotchFilter", "dc_filter", "InitAGC", "DoAGC", "InitNoiseReduction",
+                 "processNoiseReduction", "CWDecoder_Init", "CWDecoder_Process", "getPhraseFromFrequency",
+                 "getFrequencyFromPhrase", "FPGA_Init", "FPGA_fpgadata_iqclock", "FPGA_fpgadata_stuffclock",
+                 "FPGA_Audio_Buffer_SPEC_I", "FPGA_Audio_Buffer_VOICE_Q", "FPGA_Audio_SendBuffer_I",
+                 "FPGA_Audio_Buffer_Index", "FPGA_Audio_Buffer_I_tmp", "Processor_AudioBuffer_A", "Processor_AudioBuffer_B",
+                 "FFTInput_I", "FFTInput_Q", "TRX"):
+        assert must in names, must
+    for n in names:
+        assert hasattr(L, n), "missing export " + n

@@ -749,4 +749,44 @@ __global__ __launch_bounds__(64) void ddc_audio_tx(AudioState *__restrict__ stat
     x.alc_gain = alc; x.fm_hpf_a = fa; x.fm_hpf_b = fb; x.fm_accum = facc; x.max_amplitude = mxa;
 }
 
+/* Operator settings that do not select a filter, changed without touching the
+ * running state (the firmware just reads TRX.* on the next block). */
+__global__ void ddc_audio_update_k(AudioState *__restrict__ states, uint32_t lo, uint32_t hi, ddc_audio_params p)
+{
+    const uint32_t ch = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= hi) return;
+    AudioState &s = states[ch];
+    s.p = p;
+    s.agc_up = 500.0f / (float)p.agc_speed;
+    s.agc_down = s.agc_up / 10.0f;
+}
+
+/* ---- single stages, for callers that drive the firmware's fine-grained functions ---- */
+
+/* One stage of the RX audio path on one channel's state, one thread:
+ * DDC_STAGE_DC   dc_filter(buf, n, slot = arg)              audio_filters.c:358-373
+ * DDC_STAGE_AGC  DoAGC(buf, 192)                            agc.c:21-67
+ * DDC_STAGE_DNR  processNoiseReduction(buf -> buf), 64      noise_reduction.c:19-37
+ * DDC_STAGE_CW   CWDecoder_Process(buf), 192, clock arg ms  cw_decoder.c:56-174 */
+__global__ void ddc_audio_stage_k(AudioState *__restrict__ states, uint32_t ch, int stage, int arg,
+                                  float *__restrict__ buf, int n)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    AudioState &s = states[ch];
+    if (stage == DDC_STAGE_DC) {
+        for (int i = 0; i < n; i++) buf[i] = dc_step(s, arg, buf[i]);
+    } else if (stage == DDC_STAGE_AGC) {
+        agc_block(s, buf);
+    } else if (stage == DDC_STAGE_DNR) {
+        for (int i = 0; i < kASub; i++) s.lms_ref[s.ref_new + i] = buf[i];
+        lms_block(s, buf);
+        s.ref_old += kASub;
+        if (s.ref_old >= 128) s.ref_old = 0;
+        s.ref_new = s.ref_old + kASub;
+        if (s.ref_new >= 128) s.ref_new = 0;
+    } else if (stage == DDC_STAGE_CW) {
+        cw_block(s, buf, (int64_t)arg);
+    }
+}
+
 } // namespace ddc

@@ -54,6 +54,7 @@ struct ddc_ctx {
     uint32_t fft_zoom_all = 1;         // common zoom factor of all channels (0 = mixed)
     std::vector<uint8_t> audio_ready;  // per channel: ddc_audio_configure seen
     std::vector<uint8_t> zoom_of;      // per channel: configured FFT zoom
+    std::vector<ddc_audio_params> audio_cfg; // per channel: what ddc_audio_configure was given
     float2 *d_fft_work = nullptr;      // [ch][n][2] prefiltered SPEC
     float *d_fft_mag = nullptr;        // [ch][frames][256]
     size_t fft_cap = 0;                // frames per channel d_fft_mag holds
@@ -256,6 +257,7 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     }
     ctx->audio_ready.assign(nch, 0);
     ctx->zoom_of.assign(nch, 1);
+    ctx->audio_cfg.assign(nch, ddc_audio_params{});
     CREATE_TRY(hipMalloc(&ctx->d_audio, nch * sizeof(ddc::AudioState)));
     CREATE_TRY(hipMemsetAsync(ctx->d_audio, 0, nch * sizeof(ddc::AudioState), ctx->stream));
     CREATE_TRY(hipMalloc(&ctx->d_zoom, nch * sizeof(ddc::ZoomState)));
@@ -715,9 +717,31 @@ int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p
         std::vector<ddc::TxAudioState> all(hi - lo, ts);
         HIP_TRY(ctx, hipMemcpy(ctx->d_audio_tx + lo, all.data(), all.size() * sizeof ts, hipMemcpyHostToDevice));
     }
-    for (size_t c = lo; c < hi; c++) { ctx->audio_ready[c] = 1; ctx->zoom_of[c] = (uint8_t)zs.zoom; }
+    for (size_t c = lo; c < hi; c++) { ctx->audio_ready[c] = 1; ctx->zoom_of[c] = (uint8_t)zs.zoom; ctx->audio_cfg[c] = *p; }
     ctx->fft_zoom_all = ctx->zoom_of[0];
     for (uint8_t zv : ctx->zoom_of) if (zv != ctx->zoom_of[0]) ctx->fft_zoom_all = 0;
+    return 0;
+}
+
+int ddc_audio_update(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (!p) return fail(ctx, -EINVAL, "null params");
+    if (p->agc_speed == 0 || p->fft_averaging == 0) return fail(ctx, -EINVAL, "agc_speed and fft_averaging must be >= 1");
+    const uint32_t lo = channel < 0 ? 0 : (uint32_t)channel;
+    const uint32_t hi = channel < 0 ? ctx->cfg.n_channels : lo + 1;
+    for (uint32_t c = lo; c < hi; c++) {
+        const ddc_audio_params &q = ctx->audio_cfg[c];
+        if (!ctx->audio_ready[c]) return fail(ctx, -EINVAL, "ddc_audio_configure has not been called for this channel");
+        if (q.mode != p->mode || q.filter_width != p->filter_width || q.hpf_pass != p->hpf_pass ||
+            q.notch_fc != p->notch_fc || (q.fft_zoom > 1 ? q.fft_zoom : 1) != (p->fft_zoom > 1 ? p->fft_zoom : 1))
+            return fail(ctx, -EINVAL, "ddc_audio_update cannot change mode, filter_width, hpf_pass, notch_fc or fft_zoom");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(ddc::ddc_audio_update_k, dim3((hi - lo + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, lo, hi, *p);
+    HIP_TRY(ctx, hipGetLastError());
+    for (uint32_t c = lo; c < hi; c++) ctx->audio_cfg[c] = *p;
     return 0;
 }
 
@@ -870,6 +894,31 @@ int ddc_audio_tx_process(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, i
     return 0;
 }
 
+int ddc_audio_stage(ddc_ctx *ctx, int32_t channel, int stage, int arg, float *buf, int n)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0 || !buf) return fail(ctx, -EINVAL, "ddc_audio_stage needs one channel and a buffer");
+    if (!ctx->audio_ready[channel]) return fail(ctx, -EINVAL, "ddc_audio_configure has not been called for this channel");
+    switch (stage) {
+    case DDC_STAGE_DC: if (n < 0 || arg < 0 || arg > 5) return fail(ctx, -EINVAL, "dc stage: slot 0..5"); break;
+    case DDC_STAGE_AGC: case DDC_STAGE_CW: if (n != 192) return fail(ctx, -EINVAL, "stage works on 192 samples"); break;
+    case DDC_STAGE_DNR: if (n != 64) return fail(ctx, -EINVAL, "noise reduction works on 64 samples"); break;
+    default: return fail(ctx, -EINVAL, "unknown stage");
+    }
+    if (n == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    rc = ensure_stage(ctx, 0, (size_t)n * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], buf, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ddc::ddc_audio_stage_k, dim3(1), dim3(64), 0, ctx->stream, ctx->d_audio, (uint32_t)channel, stage,
+                       arg, (float *)ctx->d_stage[0], n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->d_stage[0], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out)
 {
     int rc = check_channel(ctx, channel);
@@ -968,7 +1017,7 @@ std::vector<StateSeg> state_segments(ddc_ctx *ctx)
 size_t ddc_state_size(ddc_ctx *ctx)
 {
     if (!ctx) return 0;
-    size_t t = sizeof(StateHeader) + ctx->cfg.n_channels * 2; // + audio_ready, zoom_of
+    size_t t = sizeof(StateHeader) + ctx->cfg.n_channels * (2 + sizeof(ddc_audio_params)); // + audio_ready, zoom_of, audio_cfg
     for (const StateSeg &g : state_segments(ctx)) t += g.bytes;
     return t;
 }
@@ -991,6 +1040,7 @@ int ddc_state_save(ddc_ctx *ctx, void *buf, size_t size)
     }
     memcpy(p, ctx->audio_ready.data(), ctx->cfg.n_channels);
     memcpy(p + ctx->cfg.n_channels, ctx->zoom_of.data(), ctx->cfg.n_channels);
+    memcpy(p + 2 * (size_t)ctx->cfg.n_channels, ctx->audio_cfg.data(), ctx->cfg.n_channels * sizeof(ddc_audio_params));
     return 0;
 }
 
@@ -1014,6 +1064,7 @@ int ddc_state_restore(ddc_ctx *ctx, const void *buf, size_t size)
     }
     memcpy(ctx->audio_ready.data(), p, ctx->cfg.n_channels);
     memcpy(ctx->zoom_of.data(), p + ctx->cfg.n_channels, ctx->cfg.n_channels);
+    memcpy(ctx->audio_cfg.data(), p + 2 * (size_t)ctx->cfg.n_channels, ctx->cfg.n_channels * sizeof(ddc_audio_params));
     ctx->fft_zoom_all = ctx->zoom_of[0];
     for (uint8_t zv : ctx->zoom_of) if (zv != ctx->zoom_of[0]) ctx->fft_zoom_all = 0;
     // the host mirror of the tuning words

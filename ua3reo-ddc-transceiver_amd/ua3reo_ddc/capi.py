@@ -26,12 +26,13 @@ def lib_path():
 def build_native(force=False):
     """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))]
-    hdr = os.path.join(os.path.dirname(_PKG), "include", "ua3reo_ddc.h")
-    newest = max(os.path.getmtime(p) for p in srcs + [hdr])
+    inc = os.path.join(os.path.dirname(_PKG), "include")
+    hdrs = [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+    newest = max(os.path.getmtime(p) for p in srcs + hdrs)
     if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= newest:
         return _SO
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", _SO, os.path.join(_CSRC, "ddc_lib.hip")]
+           "-o", _SO, os.path.join(_CSRC, "ddc_lib.hip"), os.path.join(_CSRC, "ddc_legacy.cpp")]
     subprocess.check_call(cmd)
     return _SO
 
@@ -104,6 +105,8 @@ def lib():
     L.ddc_state_save.argtypes = [vp, vp, sz]
     L.ddc_state_restore.argtypes = [vp, vp, sz]
     L.ddc_audio_configure.argtypes = [vp, i32, vp]
+    L.ddc_audio_update.argtypes = [vp, i32, vp]
+    L.ddc_audio_stage.argtypes = [vp, i32, C.c_int, C.c_int, vp, C.c_int]
     L.ddc_audio_rx_process_dev.argtypes = [vp, vp, vp, sz, vp]
     L.ddc_audio_rx_process.argtypes = [vp, vp, vp, sz, vp]
     L.ddc_fft_process_dev.argtypes = [vp, vp, sz, vp, vp]
@@ -253,6 +256,15 @@ class Ddc:
 
     def audio_configure(self, params, channel=-1):
         self._check(self._L.ddc_audio_configure(self._h, channel, C.byref(params)))
+
+    def audio_update(self, params, channel=-1):
+        self._check(self._L.ddc_audio_update(self._h, channel, C.byref(params)))
+
+    def audio_stage(self, channel, stage, arg, buf):
+        """One firmware stage (0 dc_filter, 1 DoAGC, 2 noise reduction, 3 CW decoder) in place on float32 buf."""
+        b = np.ascontiguousarray(buf, dtype=np.float32).copy()
+        self._check(self._L.ddc_audio_stage(self._h, channel, stage, arg, _np_ptr(b), b.size))
+        return b
 
     def audio_rx_process(self, spec_iq, voice_iq):
         """Host path. spec/voice int16 [n_channels][n][2] -> int32 [n_channels][n][2] (L, R)."""
