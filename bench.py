@@ -78,29 +78,39 @@ def measured_traffic(nch, samples):
 
 
 def cpu_baseline(n_threads, samples=1 << 22, distinct=4, reps=6):
-    """The CPU oracle (scalar C restatement of the reference datapath) on a
-    bounded sample of the same workload: every thread runs the whole RX chain
-    over `distinct` synthetic channels of `samples` samples, `reps` times."""
+    """The CPU oracle (scalar C restatement of the reference datapath, built here
+    with gcc -O3 -march=native) on a bounded sample of the same workload: every
+    thread runs the whole RX chain over `distinct` synthetic channels of `samples`
+    samples, `reps` times.  Also times one thread alone."""
+    import tempfile
     import ua3reo_ddc
     from oracle import oracle
-    oracle.lib()
+    L = oracle.build_native_variant(tempfile.mkdtemp(prefix="ddc_oracle_"))
     rows = [ua3reo_ddc.pack_adc12(ua3reo_ddc.synth_adc(c, samples)) for c in range(distinct)]
     phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * c)[0] for c in range(distinct)]
     rb = len(rows[0])
     packed = np.concatenate(rows)
+    # same answers as the default build of the oracle before any timing
+    a = oracle.rx_chain_packed(packed, rb, 1, 1 << 16, phis, L=L)
+    b = oracle.rx_chain_packed(packed, rb, 1, 1 << 16, phis)
+    if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+        raise SystemExit("bench: the -march=native build of the oracle disagrees with the default build")
 
     def work(_):
         for _r in range(reps):
-            oracle.rx_chain_packed(packed, rb, distinct, samples, phis)
+            oracle.rx_chain_packed(packed, rb, distinct, samples, phis, L=L)
 
-    oracle.rx_chain_packed(packed, rb, 1, 1 << 16, phis)  # warm-up (tables, page faults)
+    t0 = time.perf_counter()
+    oracle.rx_chain_packed(packed, rb, distinct, samples, phis, L=L)
+    one = distinct * samples / (time.perf_counter() - t0) / 1e6
     t0 = time.perf_counter()
     with ThreadPoolExecutor(n_threads) as ex:
         list(ex.map(work, range(n_threads)))
     dt = time.perf_counter() - t0
     total = n_threads * reps * distinct * samples
-    return total / dt / 1e6, "%d threads x %d channel-passes x %d samples, oracle/ddc_oracle.c (gcc -O2, scalar)" % (
-        n_threads, reps * distinct, samples)
+    return total / dt / 1e6, one, "%d threads x %d channel-passes x %d samples, oracle/ddc_oracle.c " \
+        "(gcc -O3 -march=native, scalar clock-level model); host reports %d CPUs" % (
+            n_threads, reps * distinct, samples, os.cpu_count() or 0)
 
 
 def main():
@@ -270,9 +280,9 @@ def main():
         }
         if not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
-            v, sample = cpu_baseline(threads)
+            v, one, sample = cpu_baseline(threads)
             res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": threads,
-                                   "kind": "port", "sample": sample}
+                                   "kind": "port", "sample": sample, "one_thread": round(one, 1)}
         print(json.dumps(res), flush=True)
     ctx.close()
     if dist is not None:

@@ -165,14 +165,27 @@ class RxChain(_State):
         return (spec, voice, cic) if want_cic else (spec, voice)
 
 
-def rx_chain_packed(packed, row_bytes, n_channels, n, phi):
+def build_native_variant(out_dir):
+    """The same sources built for the host this runs on (gcc -O3 -march=native), for
+    timing the CPU baseline; returns a CDLL of its own, ready to use."""
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libddc_oracle_native.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-shared", "-o", so,
+                           os.path.join(_HERE, "ddc_oracle.c"), os.path.join(_HERE, "audio_oracle.c"), "-lm"])
+    L = C.CDLL(so)
+    L.orc_init.restype = None
+    L.orc_init()
+    return L
+
+
+def rx_chain_packed(packed, row_bytes, n_channels, n, phi, L=None):
     """Fresh-state RX chain over packed 12-bit rows; returns spec, voice [ch][frame][2]."""
     packed = np.ascontiguousarray(packed, dtype=np.uint8)
     phi = np.ascontiguousarray(phi, dtype=np.uint32)
     nf = n // 1024
     spec = np.zeros((n_channels, nf, 2), np.int16)
     voice = np.zeros((n_channels, nf, 2), np.int16)
-    lib().orc_rx_chain_packed(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_channels),
+    (L or lib()).orc_rx_chain_packed(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_channels),
                               C.c_size_t(n), _p(phi), _p(spec), _p(voice))
     return spec, voice
 
