@@ -246,6 +246,20 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
                                       hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
+    {
+        // Hilbert taps as the kernel wants them: reversed pairs and the two low bit planes
+        uint32_t pairs[128], odd[8] = {0}, bit1[8] = {0};
+        for (int m = 0; m < 128; m++)
+            pairs[m] = (uint32_t)(uint16_t)rx_hilb_c[255 - 2 * m] | ((uint32_t)(uint16_t)rx_hilb_c[254 - 2 * m] << 16);
+        for (int j = 0; j < 256; j++) {
+            const unsigned c = (unsigned)(int)rx_hilb_c[255 - j];
+            odd[j >> 5] |= (c & 1u) << (j & 31);
+            bit1[j >> 5] |= ((c >> 1) & 1u) << (j & 31);
+        }
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs), pairs, sizeof pairs));
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_odd), odd, sizeof odd));
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_bit1), bit1, sizeof bit1));
+    }
     ctx->h_phi.assign(nch, 0);
     {
         // power-on values of the registers (FPGA/stm32_interface.v:385-388)
@@ -441,10 +455,12 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
         adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
     ctx->carry_sel ^= 1;
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
-    ddc::ddc_rx_cic_combine<<<(total + 255) / 256, 256, 0, st>>>(ctx->d_mom, n_blk, nch, ctx->d_cic);
+    const uint32_t ctiles = (n_blk + 255) / 256;
+    ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(ctx->d_mom, n_blk, ctiles, ctx->d_cic);
     const uint32_t nfr = nch * nf;
     ddc::ddc_rx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(ctx->d_cic, n_blk, nch, ctx->d_comp, spec_iq);
-    ddc::ddc_rx_hilbert<<<(nfr + 255) / 256, 256, 0, st>>>(ctx->d_comp, nf, nch, voice_iq);
+    const uint32_t tiles = (nf + 255) / 256;
+    ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(ctx->d_comp, nf, tiles, voice_iq);
     ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_mom,
                                                  ctx->d_cic, ctx->d_comp, ctx->d_acc, ctx->d_phi, n_blk,
                                                  (uint32_t)samples);

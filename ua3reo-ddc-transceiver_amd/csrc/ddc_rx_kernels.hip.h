@@ -464,26 +464,69 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     }
 }
 
+// COEF[j][e] * b mod 2^64 with the constant split into sign, an odd factor below
+// 2^32 and a power of two: a 32 x 64 bit product and a shift instead of a full
+// 64 x 64 bit multiply (the small odd factors fold into shifts and adds).
+__host__ __device__ constexpr unsigned long long coef_abs(int j, int e)
+{
+    return COEF[j][e] < 0 ? (unsigned long long)(-COEF[j][e]) : (unsigned long long)COEF[j][e];
+}
+__host__ __device__ constexpr int coef_tz(int j, int e)
+{
+    unsigned long long m = coef_abs(j, e);
+    int k = 0;
+    while (m && !(m & 1)) { m >>= 1; k++; }
+    return k;
+}
+constexpr bool coef_odd_parts_fit()
+{
+    for (int j = 0; j < 5; j++)
+        for (int e = 0; e < 5; e++)
+            if ((coef_abs(j, e) >> coef_tz(j, e)) >> 32) return false;
+    return true;
+}
+static_assert(coef_odd_parts_fit(), "odd part of a CIC combination constant exceeds 32 bits");
+
+__device__ __forceinline__ unsigned long long coef_mul(int j, int e, unsigned long long b)
+{
+    const unsigned long long mag = coef_abs(j, e);
+    if (mag == 0) return 0;
+    const int tz = coef_tz(j, e);
+    const uint32_t odd = (uint32_t)(mag >> tz);
+    const unsigned long long lo = (unsigned long long)odd * (uint32_t)b;
+    const unsigned long long hi = (unsigned long long)(odd * (uint32_t)(b >> 32)) << 32;
+    const unsigned long long t = (lo + hi) << tz;
+    return COEF[j][e] < 0 ? 0ull - t : t;
+}
+
 /*
  * Kernel 2.  rx_cic output m of this call from the moments of windows m-5..m-1
  * (records m..m+4): y = wrap60(sum_j sum_e COEF[j][e] * B[m-1-j][e]) >> 44
  * (FPGA/rx_cic.vhd:391).  cic: [channel][kCicHist + n_blk][2] int16.
  */
-__global__ void ddc_rx_cic_combine(const unsigned long long *__restrict__ mom, uint32_t n_blk,
-                                   uint32_t n_ch, int16_t *__restrict__ cic)
+__global__ __launch_bounds__(256) void ddc_rx_cic_combine(const unsigned long long *__restrict__ mom, uint32_t n_blk,
+                                                         uint32_t tiles, int16_t *__restrict__ cic)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_ch * n_blk) return;
-    const uint32_t ch = (uint32_t)(gid / n_blk), m = (uint32_t)(gid - (uint64_t)ch * n_blk);
-    const unsigned long long *base = mom + ((size_t)ch * (kMomHist + n_blk) + m) * 10;
+    // 256 outputs of one channel need 260 consecutive records: staged through LDS
+    // so that the 80-byte records are read from memory in whole 16-byte lanes
+    __shared__ uint4 stage[260 * 5];
+    const uint32_t ch = blockIdx.x / tiles, m0 = (blockIdx.x - ch * tiles) * 256u, t = threadIdx.x;
+    const uint32_t have = kMomHist + n_blk - m0;
+    const uint32_t count = (have < 260u ? have : 260u) * 5u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(mom + ((size_t)ch * (kMomHist + n_blk) + m0) * 10);
+    for (uint32_t i = t; i < count; i += 256) stage[i] = src[i];
+    __syncthreads();
+    const uint32_t m = m0 + t;
+    if (m >= n_blk) return;
+    const unsigned long long *base = reinterpret_cast<const unsigned long long *>(stage) + (size_t)t * 10;
     unsigned long long acc[2] = {0, 0};
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const unsigned long long *rec = base + (size_t)(4 - j) * 10;
 #pragma unroll
         for (int e = 0; e < 5; e++) {
-            acc[0] += (unsigned long long)COEF[j][e] * rec[e];
-            acc[1] += (unsigned long long)COEF[j][e] * rec[5 + e];
+            acc[0] += coef_mul(j, e, rec[e]);
+            acc[1] += coef_mul(j, e, rec[5 + e]);
         }
     }
     int16_t *o = cic + ((size_t)ch * (kCicHist + n_blk) + kCicHist + m) * 2;
@@ -566,23 +609,69 @@ __global__ void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, 
 /*
  * Kernel 4.  VOICE_I = rx_hilb(e_I): wrap16(cround(wrap30(sum_k cround(c[k]*x[n-k], 1)), 14))
  * (FPGA/rx_hilb.vhd:902-935); VOICE_Q = e_Q delayed by 130 (FPGA/data_delay.v).
+ *
+ * The per-product rounding is taken out of the tap loop.  With p = c*x,
+ * cround(p, 1) = floor(p / 2) + [p = 3 mod 4], so
+ *     sum_k cround(p_k, 1) = (S - N1) / 2 + N3,
+ * S = sum p_k (a plain dot product: v_dot2 on sample pairs), N1 = number of odd
+ * products, N3 = number of products = 3 mod 4.  N1 and N3 depend only on the two
+ * low bits of taps and samples: with the samples' bit 0 / bit 1 as bit planes and
+ * the taps' as constant masks they are population counts, 8 dwords per output.
+ * Only the low 30 bits of the sum matter, so everything runs mod 2^32.
+ *
+ * A workgroup computes 256 consecutive outputs of one channel from the 511
+ * samples they reach, staged in LDS twice (the second copy one sample on, so
+ * that odd outputs also read aligned pairs) plus the two bit planes.
  */
-__global__ void ddc_rx_hilbert(const int16_t *__restrict__ comp, uint32_t nf, uint32_t n_ch,
-                               int16_t *__restrict__ voice_iq)
+__constant__ uint32_t c_hilb_pairs[128]; // {c[255-2m] | c[254-2m] << 16}
+__constant__ uint32_t c_hilb_odd[8];     // bit j of the 256-bit mask: c[255-j] & 1
+__constant__ uint32_t c_hilb_bit1[8];    // bit j: (c[255-j] >> 1) & 1
+
+__global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict__ comp, uint32_t nf, uint32_t tiles,
+                                                     int16_t *__restrict__ voice_iq)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_ch * nf) return;
-    const uint32_t ch = (uint32_t)(gid / nf), n = (uint32_t)(gid - (uint64_t)ch * nf);
-    const uint32_t *x = reinterpret_cast<const uint32_t *>(comp) +
-                        ((size_t)ch * (kCompHist + nf) + kCompHist + n);
-    uint32_t acc = 0;
-#pragma unroll 16
-    for (int k = 0; k < 256; k++) {
-        const int m = (int)c_rx_hilb_c[k] * (int)(int16_t)(x[-k] & 0xFFFFu);
-        acc += (uint32_t)((m + ((m >> 1) & 1)) >> 1);
+    __shared__ uint32_t xa[256], xb[256];
+    __shared__ uint32_t p0[17], p1[17];
+    const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * 256u, t = threadIdx.x;
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(comp) + (size_t)ch * (kCompHist + nf);
+    const uint32_t last = kCompHist + nf - 1;
+    int16_t *sa = reinterpret_cast<int16_t *>(xa), *sb = reinterpret_cast<int16_t *>(xb);
+    // tile sample j is entry n0 + 1 + j of the channel (sample n0 - 255 + j)
+#pragma unroll
+    for (uint32_t j = t; j < 512; j += 256) {
+        uint32_t e = n0 + 1 + j;
+        e = e < last ? e : last;
+        const int v = (int)(int16_t)(x[e] & 0xFFFFu);
+        sa[j] = (int16_t)v;
+        if (j) sb[j - 1] = (int16_t)v;
+        const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2);
+        if ((t & 63u) == 0) {
+            const uint32_t w = j >> 5;
+            p0[w] = (uint32_t)b0; p0[w + 1] = (uint32_t)(b0 >> 32);
+            p1[w] = (uint32_t)b1; p1[w + 1] = (uint32_t)(b1 >> 32);
+        }
     }
+    if (t == 0) { p0[16] = 0; p1[16] = 0; sb[511] = 0; }
+    __syncthreads();
+    const uint32_t n = n0 + t;
+    if (n >= nf) return;
+    const uint32_t *src = ((t & 1u) ? xb : xa) + (t >> 1);
+    int S = 0;
+#pragma unroll
+    for (int m = 0; m < 128; m++) S = dot2(src[m], c_hilb_pairs[m], S);
+    const uint32_t w0 = t >> 5, sh = t & 31u;
+    uint32_t n1 = 0, n3 = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const uint32_t a0 = __builtin_amdgcn_alignbit(p0[w0 + d + 1], p0[w0 + d], sh);
+        const uint32_t a1 = __builtin_amdgcn_alignbit(p1[w0 + d + 1], p1[w0 + d], sh);
+        const uint32_t both = a0 & c_hilb_odd[d];
+        n1 += __popc(both);
+        n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
+    }
+    const uint32_t acc = (((uint32_t)S - n1) >> 1) + n3;
     const int16_t vi = (int16_t)cround32(acc, 14, 30);
-    const int16_t vq = (int16_t)((int)x[-130] >> 16);
+    const int16_t vq = (int16_t)((int)x[kCompHist + n - 130] >> 16);
     reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
         (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
 }
