@@ -105,6 +105,7 @@ int build_nco_table(std::vector<uint2> &tab)
         const long sf = rnd_half_away(8191.0 * std::sin(two_pi * fi / 4194304.0));
         const long cf = rnd_half_away(8191.0 * std::cos(two_pi * fi / 4194304.0));
         if ((long)((fi * DDC_SF_K + DDC_SF_R) >> 24) != sf || cf != 8191) return -1;
+        if ((long)((32u * fi * DDC_SF16_K + DDC_SF16_R) >> 24) != sf) return -1;
     }
     return 0;
 }

@@ -82,16 +82,32 @@ __device__ __forceinline__ int dot2_sconst(unsigned a, unsigned w, int c)
     return r;
 }
 
-// NCO, first half: coarse-table fetch and the packed {8191, fine sine} operand.
-// tab: 2048 coarse entries {2*sc | 2*cc<<16, 2*cc | (-2*sc)<<16}.  acc32 holds
-// the 22-bit phase accumulator in its top 22 bits, so the natural 32-bit wrap is
-// the accumulator's wrap.
-__device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc32, uint2 &e, uint32_t &w)
+// Fine sine of the NCO from the fine phase f (11 bits) given as 32 f in a 16-bit
+// half: (32 f * 6433 + 2^23) >> 24 reproduces the fine ROM round(8191 sin(2 pi f / 2^22))
+// for every f (checked on the host when a ctx is created).
+#define DDC_SF16_K 6433u
+#define DDC_SF16_R 8388608u
+
+// signed bit-field extract kept as one instruction (the compiler otherwise folds
+// it into a shift of the multiplicand and pays for that in the 12-bit unpack)
+template <int OFF, int W>
+__device__ __forceinline__ int sbfe_c(int v)
 {
-    const uint32_t off = (acc32 >> 18) & 0x3FF8u;
+    int r;
+    asm("v_bfe_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(OFF), "n"(W));
+    return r;
+}
+
+// NCO, first half: coarse-table fetch and the packed {8191, fine sine} operand.
+// tab: 2048 coarse entries {2*sc | 2*cc<<16, 2*cc | (-2*sc)<<16}.  acc27 holds
+// the 22-bit phase accumulator in bits 26..5 (bits above are ignored), so its low
+// half is 32 * fine phase, ready for a 16-bit multiply-add.
+__device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc27, uint2 &e, uint32_t &w)
+{
+    const uint32_t off = (acc27 >> 13) & 0x3FF8u;
     e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off);
-    const uint32_t fi = __builtin_amdgcn_ubfe(acc32, 10, 11);
-    const uint32_t t = __umul24(fi, DDC_SF_K) + DDC_SF_R;     // t >> 24 = fine sine (0..25)
+    uint32_t t; // t >> 24 = fine sine (0..25)
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(t) : "v"(acc27), "s"(DDC_SF16_K), "v"(DDC_SF16_R));
     w = __builtin_amdgcn_perm(t, 0x1FFFu, 0x0C070100u);       // {8191, t>>24}
 }
 
@@ -104,8 +120,8 @@ __device__ __forceinline__ void nco_finish(const uint2 e, uint32_t w, int adc, i
     const int c = dot2_sconst(e.y, w, 8192);
     const int pi = __mul24(adc, s >> 16);
     const int pq = __mul24(adc, c >> 16);
-    xi = __builtin_amdgcn_sbfe(pi, 8, 15);
-    xq = __builtin_amdgcn_sbfe(pq, 8, 15);
+    xi = sbfe_c<8, 15>(pi);
+    xq = sbfe_c<8, 15>(pq);
 }
 
 __device__ __forceinline__ void nco_mix(const uint2 *tab, uint32_t acc32, int adc, int &xi, int &xq)
@@ -133,13 +149,13 @@ __device__ __forceinline__ unsigned pack16(int lo, int hi)
 // eight 12-bit samples from three dwords
 __device__ __forceinline__ void unpack8(uint32_t d0, uint32_t d1, uint32_t d2, int (&a)[8])
 {
-    a[0] = __builtin_amdgcn_sbfe((int)d0, 0, 12);
-    a[1] = __builtin_amdgcn_sbfe((int)d0, 12, 12);
-    a[2] = __builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(d1, d0, 24), 0, 12);
-    a[3] = __builtin_amdgcn_sbfe((int)d1, 4, 12);
-    a[4] = __builtin_amdgcn_sbfe((int)d1, 16, 12);
-    a[5] = __builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(d2, d1, 28), 0, 12);
-    a[6] = __builtin_amdgcn_sbfe((int)d2, 8, 12);
+    a[0] = sbfe_c<0, 12>((int)d0);
+    a[1] = sbfe_c<12, 12>((int)d0);
+    a[2] = sbfe_c<0, 12>((int)__builtin_amdgcn_alignbit(d1, d0, 24));
+    a[3] = sbfe_c<4, 12>((int)d1);
+    a[4] = sbfe_c<16, 12>((int)d1);
+    a[5] = sbfe_c<0, 12>((int)__builtin_amdgcn_alignbit(d2, d1, 28));
+    a[6] = sbfe_c<8, 12>((int)d2);
     a[7] = (int)d2 >> 20;
 }
 
@@ -334,8 +350,11 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     const bool active = g < total_blocks;
     const uint32_t gc = active ? g : total_blocks - 1;
     const uint32_t ch = gc / n_blk, b = gc - ch * n_blk;
-    const uint32_t phi32 = phi32v[ch];
-    uint32_t acc32 = acc0[ch] + (b * (uint32_t)kBlk) * phi32;
+    // phase and increment come in shifted left by 10 (32-bit wrap = accumulator
+    // wrap); the sample loop runs on the << 5 form nco_fetch wants
+    const uint32_t phi_in = phi32v[ch];
+    const uint32_t phi32 = phi_in >> 5;
+    uint32_t acc32 = (acc0[ch] + (b * (uint32_t)kBlk) * phi_in) >> 5;
 
 #pragma unroll
     for (int j = 0; j < 8; j++) lds_dma16(src[j], &lines[(wave_base + 8 * j) * 8]);
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
                 adc + (size_t)ch * row_bytes + (size_t)b * kBlkBytes - 12);
             int a[8];
             unpack8(p[0], p[1], p[2], a);
-            uint32_t ph = acc0[ch] + (b * (uint32_t)kBlk - 6u) * phi32;
+            uint32_t ph = (acc0[ch] + (b * (uint32_t)kBlk - 6u) * phi_in) >> 5;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 int xi0, xq0, xi1, xq1;

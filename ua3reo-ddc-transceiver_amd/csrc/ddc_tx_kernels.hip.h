@@ -132,8 +132,10 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
     wq.init(cq);
     const long long T = 512ll * n96;
     const long long t0 = 512ll * g - 504;
-    const uint32_t phi32 = phi32v[ch];
-    uint32_t ph = acc0[ch] + (uint32_t)(unsigned long long)(t0 - 2) * phi32;
+    // stored phase / increment are << 10; the sample loop runs on the << 5 form of nco_fetch
+    const uint32_t phi_in = phi32v[ch];
+    const uint32_t phi32 = phi_in >> 5;
+    uint32_t ph = (acc0[ch] + (uint32_t)(unsigned long long)(t0 - 2) * phi_in) >> 5;
     uint16_t *row = dac + (size_t)ch * (size_t)T;
 #pragma unroll 1
     for (int grp = 0; grp < 64; grp++) {
