@@ -188,6 +188,15 @@ struct Cascade {
         t30 += mu[3]; t31 += 17ll * mu[3];
         t40 += mu[4];
     }
+    // Adds local moments mu to the last step taken: every T[i][q] of a step sees mu[i] once.
+    __device__ __forceinline__ void inject_last(const int (&mu)[5])
+    {
+        t00 += mu[0]; t01 += mu[0]; t02 += mu[0]; t03 += mu[0]; t04 += mu[0];
+        t10 += mu[1]; t11 += mu[1]; t12 += mu[1]; t13 += mu[1];
+        t20 += mu[2]; t21 += mu[2]; t22 += mu[2];
+        t30 += mu[3]; t31 += mu[3];
+        t40 += mu[4];
+    }
     // B[e] = sum_{i<=e} sum_{q<=e-i} GAM[e-i][q] * T[i][q]   (mod 2^64)
     __device__ __forceinline__ void moments(unsigned long long (&B)[5]) const
     {
@@ -405,14 +414,19 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
         group8<1>(tab, v0.w, v1.x, v1.y, acc32, phi32, mi, mq, last_i, last_q);
         group8<2>(tab, v1.z, v1.w, v2.x, acc32, phi32, mi, mq, last_i, last_q);
         group8<3>(tab, v2.y, v2.z, v2.w, acc32, phi32, mi, mq, last_i, last_q);
-        if (a == kChunksPerBlk - 1) { // the newest five samples open the next window
-            tail5_acc<-1>(last_i, mi);
-            tail5_acc<-1>(last_q, mq);
-        }
         ci.step(mi);
         cq.step(mq);
     }
 #undef DDC_PIECE
+    {
+        // the newest five samples of the block open the next window: take them back
+        // out of the last step
+        int mi[5] = {0, 0, 0, 0, 0}, mq[5] = {0, 0, 0, 0, 0};
+        tail5_acc<-1>(last_i, mi);
+        tail5_acc<-1>(last_q, mq);
+        ci.inject_last(mi);
+        cq.inject_last(mq);
+    }
 
     // The five samples before this block open its window.  They are the last
     // samples of the block to the left: its thread hands their mixer outputs over
