@@ -574,7 +574,8 @@ int ddc_tx_process_dev(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t
     ddc::ddc_tx_load_history<<<(uint32_t)nch, 64, 0, st>>>(tx.d_hist_y, tx.d_ybuf, n96);
     const uint32_t nfr = (uint32_t)(nch * n48);
     ddc::ddc_tx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(iq48k, tx.d_hist_x, n48, (uint32_t)nch, tx.d_ybuf);
-    const uint32_t total = (uint32_t)(nch * (n96 + 1));
+    if ((unsigned long long)nch * n96 >= (1ull << 26)) return fail(ctx, -EINVAL, "more than 2^26 blocks of 512 DAC samples in one call");
+    const uint32_t total = (uint32_t)(nch * n96);
     ddc::ddc_tx_duc<<<(total + 255) / 256, 256, 0, st>>>(tx.d_ybuf, n96, total, tx.d_acc, ctx->d_phi, dac14,
                                                         ctx->d_nco_tab);
     ddc::ddc_tx_save_history<<<(uint32_t)nch, 64, 0, st>>>(tx.d_hist_x, tx.d_hist_y, iq48k, tx.d_ybuf, tx.d_acc,

@@ -84,6 +84,17 @@ struct PolyWalk {
         q1 = c[1] + q2;
         p = c[0] + q1;
     }
+    // the same walk entered at u = 504: p and its backward differences there,
+    // nabla^k p(504) = sum_{e>=k} c[e] C(504 + e - k, e - k)
+    __device__ __forceinline__ void init_at504(const long long (&c)[5])
+    {
+        const long long k1 = 505, k2 = 127765, k3 = 21592285, k4 = 2742220195ll; // C(504 + m, m)
+        c4 = c[4];
+        q3 = c[3] + c[4] * k1;
+        q2 = c[2] + c[3] * k1 + c[4] * k2;
+        q1 = c[1] + c[2] * k1 + c[3] * k2 + c[4] * k3;
+        p = c[0] + c[1] * k1 + c[2] * k2 + c[3] * k3 + c[4] * k4;
+    }
     __device__ __forceinline__ void next()
     {
         q3 += c4;
@@ -96,27 +107,25 @@ struct PolyWalk {
 };
 
 /*
- * Segment G (= g - 1, g = 0..n96) of one channel covers DAC samples
- * t = 512 G + 8 + u, u = 0..511, of this call:
+ * One thread writes one aligned block of 512 DAC samples (1 KB) of one channel:
+ * block g (1..n96) is t = 512 (g - 1) + k, k = 0..511.  The interpolated tx_cic
+ * output is piecewise polynomial with pieces ("segments") that start 8 samples
+ * into a block:
+ *   segment G covers t = 512 G + 8 + u, u = 0..511,
  *   cic(t-3) = (sum_q p_q(u) y[G-1-q]) >> 38,  p_q(u) = sum_e COEF[q][e] C(u+e, e)
  *   dac[t]   = (((I*sin14 + Q*cos14)(phase(t-2)) >> 14) + 8191) & 0x3FFF
+ * so the first 8 samples of block g come from segment g - 2 at u = 504..511 and
+ * the other 504 from segment g - 1 at u = 0..503.
+ *
+ * The 16 bytes a thread produces per group of 8 samples are collected in LDS for
+ * 8 groups; then 8 adjacent lanes write one whole 128-byte line (the blocks are
+ * line-aligned), instead of 64 lanes writing 16 bytes each 1 KB apart.
  * ybuf: [channel][6 + n96][2]; dac: [channel][512 n96] uint16.
  */
-__global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ ybuf, uint32_t n96,
-                                                  uint32_t total, const uint32_t *__restrict__ acc0,
-                                                  const uint32_t *__restrict__ phi32v,
-                                                  uint16_t *__restrict__ dac,
-                                                  const uint2 *__restrict__ nco_tab)
+__device__ __forceinline__ void tx_segment_coeffs(const uint32_t *y, long long (&ci)[5], long long (&cq)[5])
 {
-    __shared__ uint2 tab[2048];
-    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tab[i] = nco_tab[i];
-    __syncthreads();
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const uint32_t per = n96 + 1;
-    const uint32_t ch = gid / per, g = gid - ch * per;
-    const uint32_t *y = reinterpret_cast<const uint32_t *>(ybuf) + (size_t)ch * (kTxYHist + n96) + 4 + g;
-    long long ci[5] = {0, 0, 0, 0, 0}, cq[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 5; e++) { ci[e] = 0; cq[e] = 0; }
 #pragma unroll
     for (int q = 0; q < 5; q++) {
         const uint32_t v = y[-q];
@@ -127,18 +136,68 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
             cq[e] += COEF[q][e] * yq;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ ybuf, uint32_t n96,
+                                                  uint32_t total, const uint32_t *__restrict__ acc0,
+                                                  const uint32_t *__restrict__ phi32v,
+                                                  uint16_t *__restrict__ dac,
+                                                  const uint2 *__restrict__ nco_tab)
+{
+    __shared__ uint2 tab[2048];
+    __shared__ uint4 obuf[8 * 256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave_base = tid & ~63u;
+    for (uint32_t i = tid; i < 2048; i += blockDim.x) tab[i] = nco_tab[i];
+
+    // flush targets: store j of a wave covers rows wave_base + 8 j .. + 7, lane l
+    // writing, for row 8 j + (l >> 3), the piece held in slot l & 7; offsets in
+    // 16-byte units from dac, ~0 = no such block
+    uint32_t dst16[8];
+    {
+        const uint32_t g0 = blockIdx.x * 256u + wave_base + (lane >> 3);
+        uint32_t gid = g0 < total ? g0 : total - 1;
+        uint32_t cho = gid / n96, go = gid - cho * n96;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t row = wave_base + 8u * j + (lane >> 3);
+            const uint32_t piece = (lane & 7u) ^ line_swz(row);
+            const bool ok = blockIdx.x * 256u + row < total;
+            dst16[j] = ok ? (uint32_t)(((size_t)cho * n96 + go) * 64u) + piece : 0xFFFFFFFFu;
+            if (gid + 8u < total) {
+                gid += 8u;
+                go += 8u;
+                while (go >= n96) { go -= n96; cho++; }
+            }
+        }
+    }
+
+    const uint32_t gid0 = blockIdx.x * 256u + tid;
+    const bool active = gid0 < total;
+    const uint32_t gidc = active ? gid0 : total - 1;
+    const uint32_t ch = gidc / n96, g = gidc - ch * n96 + 1; // block g = 1..n96
+    // buffer index of y[G-1] for segment G is G + 5 (six words of history in front)
+    const uint32_t *ybase = reinterpret_cast<const uint32_t *>(ybuf) + (size_t)ch * (kTxYHist + n96);
     PolyWalk wi, wq;
-    wi.init(ci);
-    wq.init(cq);
-    const long long T = 512ll * n96;
-    const long long t0 = 512ll * g - 504;
+    {
+        long long ci[5], cq[5];
+        tx_segment_coeffs(ybase + 3 + g, ci, cq); // segment g - 2
+        wi.init_at504(ci);
+        wq.init_at504(cq);
+    }
     // stored phase / increment are << 10; the sample loop runs on the << 5 form of nco_fetch
     const uint32_t phi_in = phi32v[ch];
     const uint32_t phi32 = phi_in >> 5;
-    uint32_t ph = (acc0[ch] + (uint32_t)(unsigned long long)(t0 - 2) * phi_in) >> 5;
-    uint16_t *row = dac + (size_t)ch * (size_t)T;
+    uint32_t ph = (acc0[ch] + (512u * (g - 1) - 2u) * phi_in) >> 5;
+    const uint32_t mine = tid * 8u, swz = line_swz(tid);
+    __syncthreads(); // tab is ready
 #pragma unroll 1
     for (int grp = 0; grp < 64; grp++) {
+        if (grp == 1) { // the block's own segment starts here
+            long long ci[5], cq[5];
+            tx_segment_coeffs(ybase + 4 + g, ci, cq); // segment g - 1
+            wi.init(ci);
+            wq.init(cq);
+        }
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -151,8 +210,18 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
             wi.next();
             wq.next();
         }
-        const long long t = t0 + 8 * grp;
-        if (t >= 0 && t < T) *reinterpret_cast<uint4 *>(row + t) = make_uint4(w[0], w[1], w[2], w[3]);
+        obuf[mine + (((uint32_t)grp & 7u) ^ swz)] = make_uint4(w[0], w[1], w[2], w[3]);
+        if ((grp & 7) == 7) {
+            __syncthreads();
+            const uint32_t line = (uint32_t)grp >> 3;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint4 v = obuf[(wave_base + 8u * j) * 8u + lane];
+                if (dst16[j] != 0xFFFFFFFFu)
+                    reinterpret_cast<uint4 *>(dac)[(size_t)dst16[j] + line * 8u] = v;
+            }
+            __syncthreads();
+        }
     }
 }
 
