@@ -232,3 +232,72 @@ def test_state_save_restore_resumes_bit_exact(ddc, orc):
     assert np.array_equal(a1, a2)
     with pytest.raises(ddc.DdcError):
         ddc.Ddc(3).state_restore(blob)
+
+
+def test_many_channels_few_blocks(ddc, orc):
+    """Workgroups that straddle many channels: 300 channels x 2 blocks of 512,
+    rows padded beyond the samples; plus an empty call."""
+    n_ch, samples = 300, 1024
+    rng = np.random.default_rng(71)
+    adc = rng.integers(-2048, 2048, size=(n_ch, 3 * samples)).astype(np.int16)
+    phis = rng.integers(0, 1 << 22, n_ch).astype(np.uint32)
+    d = ddc.Ddc(n_ch)
+    d.tune_many(phis)
+    outs = []
+    for k in range(3):
+        rows = np.zeros((n_ch, 1536 + 256), np.uint8)  # pitch larger than the data
+        for c in range(n_ch):
+            rows[c, :1536] = ddc.pack_adc12(adc[c, k * samples:(k + 1) * samples])
+        outs.append(d.rx_process(rows, samples))
+        s0, v0 = d.rx_process(rows, 0)  # nothing to do, state untouched
+        assert s0.shape == (n_ch, 0, 2)
+    spec = np.concatenate([o[0] for o in outs], axis=1)
+    voice = np.concatenate([o[1] for o in outs], axis=1)
+    for c in (0, 1, 127, 128, 255, 256, 299):
+        ws, wv = orc.RxChain(int(phis[c])).run(adc[c])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+
+
+def test_full_size_shard_properties(ddc, orc):
+    """BASELINE config 5, one GPU's shard (1024 channels x 2^20 samples), checked by
+    properties that do not need the oracle at full size: one call equals four
+    quarter calls, two channels fed the same row and tuning word agree, and three
+    channels match the oracle on their first 65536 samples."""
+    import torch
+    n_ch, samples = 1024, 1 << 20
+    rb = samples // 2 * 3
+    g = torch.Generator(device="cuda").manual_seed(99)
+    adc = torch.randint(0, 256, (n_ch, rb), dtype=torch.uint8, device="cuda", generator=g)
+    adc[1023] = adc[0]
+    phis = [(977 * c + 605867) % (1 << 22) for c in range(n_ch)]
+    phis[1023] = phis[0]
+    nf = samples // 1024
+
+    def run(parts):
+        d = ddc.Ddc(n_ch)
+        d.tune_many(phis)
+        spec = torch.zeros((n_ch, nf, 2), dtype=torch.int16, device="cuda")
+        voice = torch.zeros_like(spec)
+        step = samples // parts
+        for k in range(parts):
+            # a quarter call reads a column slice: same pitch, shifted base
+            s_k = torch.zeros((n_ch, nf // parts, 2), dtype=torch.int16, device="cuda")
+            v_k = torch.zeros_like(s_k)
+            d.rx_process_dev(adc.data_ptr() + k * (step // 2 * 3), rb, step, s_k.data_ptr(), v_k.data_ptr())
+            d.sync()
+            spec[:, k * (nf // parts):(k + 1) * (nf // parts)] = s_k
+            voice[:, k * (nf // parts):(k + 1) * (nf // parts)] = v_k
+        d.close()
+        return spec, voice
+
+    s1, v1 = run(1)
+    s4, v4 = run(4)
+    assert torch.equal(s1, s4) and torch.equal(v1, v4)
+    assert torch.equal(s1[0], s1[1023]) and torch.equal(v1[0], v1[1023])
+    assert not torch.equal(s1[0], s1[1])
+    ns = 1 << 16
+    for c in (0, 511, 1022):
+        x = ddc.unpack_adc12(adc[c, : ns // 2 * 3].cpu().numpy(), ns)
+        ws, wv = orc.RxChain(phis[c]).run(x)
+        assert np.array_equal(s1[c, : ns // 1024].cpu().numpy(), ws)
+        assert np.array_equal(v1[c, : ns // 1024].cpu().numpy(), wv)

@@ -36,4 +36,10 @@ cat $out/bench_cfg3.json
 step config-4-shape
 timeout -k 10 300 python3 bench.py --workload tx --channels 256 --samples 4194304 --steps 10 > $out/bench_cfg4.json 2> $out/bench_cfg4.err || { echo "cfg4 failed"; tail -20 $out/bench_cfg4.err; exit 1; }
 cat $out/bench_cfg4.json
+step config-4-pmc
+BENCH_ARGS="--workload tx --channels 256 --samples 4194304" bash tools/pmc_pass.sh txw WRITE_SIZE && BENCH_ARGS="--workload tx --channels 256 --samples 4194304" bash tools/pmc_pass.sh txf FETCH_SIZE || { echo "tx pmc failed"; exit 1; }
+python3 tools/pmc_summary.py gpurun_out/pmc_txw > $out/pmc_summary_tx.txt
+python3 tools/pmc_summary.py gpurun_out/pmc_txf >> $out/pmc_summary_tx.txt
+rm -rf gpurun_out/pmc_txw gpurun_out/pmc_txf
+cat $out/pmc_summary_tx.txt
 echo "== done"

@@ -38,5 +38,11 @@ for f in ("bench_cfg3.json", "bench_cfg4.json"):
         out.append(open(d + "/" + f).read().strip())
     except OSError:
         pass
+try:
+    out.append("")
+    out.append("# PMC passes on the TX shape (bench.py --workload tx --channels 256 --samples 4194304), KiB per dispatch")
+    out.append(open(d + "/pmc_summary_tx.txt").read().rstrip())
+except OSError:
+    pass
 open(out_path, "w").write("\n".join(out) + "\n")
 print("wrote", out_path)
