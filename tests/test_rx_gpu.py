@@ -283,6 +283,7 @@ def test_full_size_shard_properties(ddc, orc):
             # a quarter call reads a column slice: same pitch, shifted base
             s_k = torch.zeros((n_ch, nf // parts, 2), dtype=torch.int16, device="cuda")
             v_k = torch.zeros_like(s_k)
+            torch.cuda.synchronize()  # the ctx has its own stream: torch's fills must have landed
             d.rx_process_dev(adc.data_ptr() + k * (step // 2 * 3), rb, step, s_k.data_ptr(), v_k.data_ptr())
             d.sync()
             spec[:, k * (nf // parts):(k + 1) * (nf // parts)] = s_k

@@ -119,6 +119,7 @@ def test_tx_full_size_properties(ddc, orc):
         for k in range(parts):
             part = iq[:, k * step:(k + 1) * step].contiguous()
             o_k = torch.zeros((n_ch, 1024 * step), dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()  # the ctx has its own stream: torch's fills must have landed
             d.tx_process_dev(part.data_ptr(), step, o_k.data_ptr())
             d.sync()
             out[:, 1024 * k * step:1024 * (k + 1) * step] = o_k
