@@ -325,6 +325,7 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+    torch.cuda.synchronize()  # torch filled iq / dac on its own stream
     for _ in range(args.warmup):
         ctx.tx_process_dev(iq.data_ptr(), n_iq, dac.data_ptr())
     ctx.sync()
