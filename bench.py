@@ -197,6 +197,7 @@ def main():
         chk_ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
         chk_ctx.tune_many(phis)
         chk_out = torch.zeros((2, nch, ns // 1024, 2), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
         chk_ctx.rx_process_dev(adc.data_ptr(), rb, ns, chk_out[0].data_ptr(), chk_out[1].data_ptr())
         chk_ctx.sync()
         for c in sorted({0, nch // 2, nch - 1}):
@@ -314,6 +315,7 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
         dac_k = torch.zeros((nch, k * 1024), dtype=torch.int16, device=dev)
         chk = ua3reo_ddc.Ddc(nch, device=local_rank)
         chk.tune_many(phis)
+        torch.cuda.synchronize()
         chk.tx_process_dev(iq_k.data_ptr(), k, dac_k.data_ptr())
         chk.sync()
         for c in sorted({0, nch // 2, nch - 1}):
