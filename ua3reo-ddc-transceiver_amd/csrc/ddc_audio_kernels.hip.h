@@ -440,14 +440,25 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
         keep = 512 - 512 / M;
         for (uint32_t i = 0; i < keep; i++) dst[i] = z.hist[i];
     }
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t v = src[i];
+    // 16 samples per trip: four 16-byte loads in flight instead of one dword per
+    // dependent step (n is a multiple of 512, rows are 16-byte aligned)
+    for (uint32_t i0 = 0; i0 < n; i0 += 16) {
+        uint4 in4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) in4[k] = reinterpret_cast<const uint4 *>(src + i0)[k];
+        const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
+                                  in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
+        float2 out[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+        const uint32_t i = i0 + k;
+        const uint32_t v = in[k];
         float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
         if (swap) { const float t = fi; fi = fq; fq = t; }
         { const float d = fi - dx4; const float a = A1 * dy4; const float o = d + a; dx4 = fi; dy4 = o; fi = o; }
         { const float d = fq - dx5; const float a = A1 * dy5; const float o = d + a; dx5 = fq; dy5 = o; fq = o; }
         if (notch) { fi = biquad_step(c, ni, fi); fq = biquad_step(c, nq, fq); }
-        if (M == 1) { dst[i] = make_float2(fi, fq); continue; }
+        if (M == 1) { out[k] = make_float2(fi, fq); continue; }
 #pragma unroll
         for (int sg = 0; sg < 4; sg++) { // arm_biquad_cascade_df1_f32: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2
             const float b0 = zc[5 * sg], b1 = zc[5 * sg + 1], b2 = zc[5 * sg + 2], a1 = zc[5 * sg + 3], a2 = zc[5 * sg + 4];
@@ -465,6 +476,12 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
 #pragma unroll
             for (int k = 0; k < 4; k++) { ai += wi[k] * zf[k]; aq += wq[k] * zf[k]; }
             dst[keep + i / M] = make_float2(ai, aq);
+        }
+        }
+        if (M == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                reinterpret_cast<float4 *>(dst + i0)[k] = make_float4(out[2 * k].x, out[2 * k].y, out[2 * k + 1].x, out[2 * k + 1].y);
         }
     }
     s.dc_x[4] = dx4; s.dc_y[4] = dy4; s.dc_x[5] = dx5; s.dc_y[5] = dy5;

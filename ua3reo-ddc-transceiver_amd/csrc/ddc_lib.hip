@@ -826,6 +826,7 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
     if (n_frames == 0) return 0;
     if (!spec_iq) return fail(ctx, -EINVAL, "null buffer");
     if (n_frames % 512) return fail(ctx, -EINVAL, "n_frames must be a multiple of 512");
+    if ((uintptr_t)spec_iq % 16) return fail(ctx, -EINVAL, "spec_iq must be 16-byte aligned");
     const size_t fpc = n_frames / 512;
     const size_t nch = ctx->cfg.n_channels;
     if (nch * fpc > 0x7FFFFFFFu) return fail(ctx, -EINVAL, "too many FFT frames in one call");
