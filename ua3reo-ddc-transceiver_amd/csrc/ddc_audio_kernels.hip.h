@@ -326,20 +326,52 @@ __device__ __forceinline__ int32_t f2i_sat(float v)
     return (int32_t)v;
 }
 
+// arm_iir_lattice_f32 step with the state and the coefficient tables in registers
+// (N is 6, 7 or 11; the arrays are sized for the longest filter)
+template <int N>
+__device__ __forceinline__ float lattice_reg(float (&g)[11], const float (&k)[11], const float (&v)[12], float x)
+{
+    float fcurr = x, fnext = x, acc = 0.0f, ng[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float gcurr = g[i];
+        fnext = fcurr - k[i] * gcurr;
+        const float gnext = fnext * k[i] + gcurr;
+        acc += gnext * v[i];
+        ng[i] = gnext;
+        fcurr = fnext;
+    }
+    acc += fnext * v[N];
+#pragma unroll
+    for (int i = 0; i + 1 < N; i++) g[i] = ng[i + 1];
+    g[N - 1] = fnext;
+    return acc;
+}
+
+constexpr int kABiPitch = kABlock + 1; // LDS row pitch in floats: rows of neighbouring lanes start one bank apart
+
 /*
  * processRxAudio for every channel: thread = channel, sequential over the
  * n_frames / 192 blocks of the call.  spec_iq / voice_iq: [channel][n_frames][2]
  * int16; audio: [channel][n_frames][2] int32 (left = I, right = Q).
+ *
+ * Everything that runs sample by sample in the firmware (DC blockers, gain, both
+ * lattice pairs, demodulator, notch, S-meter) runs here in one pass with its
+ * state in registers; the block of 192 demodulated samples that the block-wise
+ * stages need (noise reduction, AGC peak and ramp, CW decoder) waits in LDS.
  */
 __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ states, uint32_t n_ch,
                                                    const int16_t *__restrict__ spec_iq,
                                                    const int16_t *__restrict__ voice_iq, uint32_t n_frames,
                                                    int32_t *__restrict__ audio)
 {
+    __shared__ float blockbuf[64 * kABiPitch];
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
-    AudioState s = states[ch];
-    const int m = s.p.mode;
+    AudioState &s = states[ch];
+    float *bi = &blockbuf[threadIdx.x * kABiPitch];
+    const ddc_audio_params p = s.p;
+    const int m = p.mode;
     const bool use_spec = (m == DDC_MODE_IQ || m == DDC_MODE_NFM || m == DDC_MODE_WFM || m == DDC_MODE_AM);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(use_spec ? spec_iq : voice_iq) + (size_t)ch * n_frames;
     int32_t *dst = audio + (size_t)ch * n_frames * 2;
@@ -347,42 +379,116 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
     const bool ssb_u = (m == DDC_MODE_USB || m == DDC_MODE_CW_U || m == DDC_MODE_DIGI_U);
     const bool hpf = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_USB || m == DDC_MODE_CW_U);
     const bool fm = (m == DDC_MODE_NFM || m == DDC_MODE_WFM);
-    const bool chain = ssb_l || ssb_u || fm || m == DDC_MODE_AM;
-    const float *lk = ddc_lpf_k[s.lpf_idx], *lv = ddc_lpf_v[s.lpf_idx];
-    const float *hk = ddc_hpf_k[s.hpf_idx], *hv = ddc_hpf_v[s.hpf_idx];
-    const float vol = s.p.mute ? 0.0f : (float)s.p.volume / 100.0f;
-    float bi[kABlock], bq[kABlock];
+    const bool am = m == DDC_MODE_AM;
+    const bool chain = ssb_l || ssb_u || fm || am;
+    const bool lpf = chain && p.filter_width > 0;
+    const bool notch = chain && !fm && p.notch;
+    const int lpf_n = s.lpf_n;
+    const float vol = p.mute ? 0.0f : (float)p.volume / 100.0f;
+    const float rf_gain = p.rf_gain;
+    const bool swap = p.iq_swap;
+    // coefficients and per-sample state into registers
+    float lk[11], lv[12], hk[11], hv[12];
+#pragma unroll
+    for (int i = 0; i < 11; i++) { lk[i] = ddc_lpf_k[s.lpf_idx][i]; hk[i] = i < 6 ? ddc_hpf_k[s.hpf_idx][i] : 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lv[i] = ddc_lpf_v[s.lpf_idx][i]; hv[i] = i < 7 ? ddc_hpf_v[s.hpf_idx][i] : 0.0f; }
+    float ghi[11], ghq[11], gli[11], glq[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) { ghi[i] = s.hpf_i.g[i]; ghq[i] = s.hpf_q.g[i]; gli[i] = s.lpf_i.g[i]; glq[i] = s.lpf_q.g[i]; }
+    float dx0 = s.dc_x[0], dy0 = s.dc_y[0], dx1 = s.dc_x[1], dy1 = s.dc_y[1];
+    float nc[5], nd[2] = { s.notch_d[0], s.notch_d[1] };
+#pragma unroll
+    for (int i = 0; i < 5; i++) nc[i] = s.notch_c[i];
+    float sm_max = s.smeter_max, sm_min = s.smeter_min;
+    float fm_lpf = s.fm_lpf_prev, fm_ha = s.fm_hpf_a, fm_hb = s.fm_hpf_b, fm_ip = s.fm_i_prev, fm_qp = s.fm_q_prev;
+    float fm_avg = s.fm_sql_avg;
+    uint32_t fm_cnt = s.fm_sql_count, squelched = s.squelched, blocks = s.blocks;
+    const float A1 = 0.99951171875f; // 1 - 2^-11
+
     for (uint32_t b0 = 0; b0 + kABlock <= n_frames; b0 += kABlock) {
-        for (int i = 0; i < kABlock; i++) {
-            const uint32_t v = src[b0 + i];
-            float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
-            if (s.p.iq_swap) { const float t = fi; fi = fq; fq = t; }
-            fi = dc_step(s, 0, fi) * s.p.rf_gain;
-            fq = dc_step(s, 1, fq) * s.p.rf_gain;
-            if (chain) {
-                if (hpf) { lattice_step(s.hpf_i, 6, hk, hv, fi); lattice_step(s.hpf_q, 6, hk, hv, fq); }
-                if (s.p.filter_width > 0) { lattice_step(s.lpf_i, s.lpf_n, lk, lv, fi); lattice_step(s.lpf_q, s.lpf_n, lk, lv, fq); }
-                if (ssb_l) fi = fi - fq;
-                else if (ssb_u) fi = fi + fq;
-                else if (m == DDC_MODE_AM) {
-                    const float p = fi * fi + fq * fq;
-                    fi = p >= 0.0f ? sqrtf(p) : 0.0f;
+        float first_angle = 0;
+        for (int i0 = 0; i0 < kABlock; i0 += 16) { // 16 samples per trip: the loads and stores go in 16-byte pieces
+            uint4 in4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) in4[k] = reinterpret_cast<const uint4 *>(src + b0 + i0)[k];
+            const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
+                                      in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
+            int32_t out[32];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t v = in[k];
+                float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
+                if (swap) { const float t = fi; fi = fq; fq = t; }
+                { const float d = fi - dx0; const float a = A1 * dy0; const float o = d + a; dx0 = fi; dy0 = o; fi = o * rf_gain; }
+                { const float d = fq - dx1; const float a = A1 * dy1; const float o = d + a; dx1 = fq; dy1 = o; fq = o * rf_gain; }
+                if (chain) {
+                    if (hpf) { fi = lattice_reg<6>(ghi, hk, hv, fi); fq = lattice_reg<6>(ghq, hk, hv, fq); }
+                    if (lpf) {
+                        if (lpf_n == 11) { fi = lattice_reg<11>(gli, lk, lv, fi); fq = lattice_reg<11>(glq, lk, lv, fq); }
+                        else { fi = lattice_reg<7>(gli, lk, lv, fi); fq = lattice_reg<7>(glq, lk, lv, fq); }
+                    }
+                    if (ssb_l) fi = fi - fq;
+                    else if (ssb_u) fi = fi + fq;
+                    else if (am) {
+                        const float pw = fi * fi + fq * fq;
+                        fi = pw >= 0.0f ? sqrtf(pw) : 0.0f;
+                    } else { // DemodulateFM, audio_processor.c:509-559
+                        const float y = (fq * fm_ip) - (fi * fm_qp);
+                        const float x = (fi * fm_ip) + (fq * fm_qp);
+                        const float angle = atan2f(y, x);
+                        if (i0 + k == 0) first_angle = angle;
+                        const float a = fm_lpf + (0.05f * (angle - fm_lpf));
+                        fm_lpf = a;
+                        fm_qp = fq;
+                        fm_ip = fi;
+                        if (!squelched || !p.fm_sql_threshold) {
+                            if (m == DDC_MODE_WFM)
+                                fi = angle / kPiF * 16384.0f;
+                            else {
+                                const float bb = 0.96f * (fm_hb + a - fm_ha);
+                                fm_ha = a;
+                                fm_hb = bb;
+                                fi = bb * 30000.0f;
+                            }
+                        } else
+                            fi = 0;
+                    }
+                    if (notch) fi = biquad_step(nc, nd, fi);
                 }
+                if (fi > sm_max) sm_max = fi;
+                if (fq > sm_max) sm_max = fq;
+                if (fi < sm_min) sm_min = fi;
+                if (fq < sm_min) sm_min = fq;
+                if (chain) bi[i0 + k] = fi;
+                else { out[2 * k] = f2i_sat(fi * vol); out[2 * k + 1] = f2i_sat(fq * vol); }
             }
-            bi[i] = fi;
-            bq[i] = fq;
+            if (!chain) {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    reinterpret_cast<int4 *>(dst + 2 * (b0 + i0))[k] = make_int4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+            }
         }
-        if (fm) fm_block(s, bi, bq);
-        if (chain && !fm && s.p.notch)
-            for (int i = 0; i < kABlock; i++) bi[i] = biquad_step(s.notch_c, s.notch_d, bi[i]);
-        for (int i = 0; i < kABlock; i++) {
-            if (bi[i] > s.smeter_max) s.smeter_max = bi[i];
-            if (bq[i] > s.smeter_max) s.smeter_max = bq[i];
-            if (bi[i] < s.smeter_min) s.smeter_min = bi[i];
-            if (bq[i] < s.smeter_min) s.smeter_min = bq[i];
+        if (fm) { // squelch, audio_processor.c:560-588
+            fm_avg = ((1.0f - 0.005f) * fm_avg) + (0.005f * sqrtf(fabsf(first_angle)));
+            if (fm_cnt == 0) {
+                if (fm_avg > 0.7f) fm_avg = 0.7f;
+                const float bsq = fm_avg * 10.0f;
+                const int thr = p.fm_sql_threshold;
+                if (!thr) squelched = 0;
+                else if (squelched) {
+                    if (bsq <= (float)((10 - thr) - 0.3f)) squelched = 0;
+                } else {
+                    if ((10.0f - thr) > 0.3f) {
+                        if (bsq > (float)((10 - thr) + 0.3f)) squelched = 1;
+                    } else if (bsq > (10.0f - (float)thr)) squelched = 1;
+                }
+                fm_cnt++; // only ever bumped here, as in the firmware
+                if (fm_cnt >= 50) fm_cnt = 0;
+            }
         }
         if (chain) {
-            if (s.p.dnr)
+            if (p.dnr)
                 for (int sb = 0; sb < kABlock / kASub; sb++) {
                     float *x = bi + sb * kASub;
                     for (int i = 0; i < kASub; i++) s.lms_ref[s.ref_new + i] = x[i];
@@ -393,16 +499,21 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
                     if (s.ref_new >= 128) s.ref_new = 0;
                 }
             agc_block(s, bi);
-            if (s.p.cw_decoder && (m == DDC_MODE_CW_L || m == DDC_MODE_CW_U)) cw_block(s, bi, 4ll * (int64_t)s.blocks);
-            for (int i = 0; i < kABlock; i++) bq[i] = bi[i];
+            if (p.cw_decoder && (m == DDC_MODE_CW_L || m == DDC_MODE_CW_U)) cw_block(s, bi, 4ll * (int64_t)blocks);
+            for (int i0 = 0; i0 < kABlock; i0 += 2) { // doRX_COPYCHANNEL + volume: left = right
+                const int32_t a = f2i_sat(bi[i0] * vol), b = f2i_sat(bi[i0 + 1] * vol);
+                *reinterpret_cast<int4 *>(dst + 2 * (b0 + i0)) = make_int4(a, a, b, b);
+            }
         }
-        for (int i = 0; i < kABlock; i++) {
-            dst[2 * (b0 + i)] = f2i_sat(bi[i] * vol);
-            dst[2 * (b0 + i) + 1] = f2i_sat(bq[i] * vol);
-        }
-        s.blocks++;
+        blocks++;
     }
-    states[ch] = s;
+#pragma unroll
+    for (int i = 0; i < 11; i++) { s.hpf_i.g[i] = ghi[i]; s.hpf_q.g[i] = ghq[i]; s.lpf_i.g[i] = gli[i]; s.lpf_q.g[i] = glq[i]; }
+    s.dc_x[0] = dx0; s.dc_y[0] = dy0; s.dc_x[1] = dx1; s.dc_y[1] = dy1;
+    s.notch_d[0] = nd[0]; s.notch_d[1] = nd[1];
+    s.smeter_max = sm_max; s.smeter_min = sm_min;
+    s.fm_lpf_prev = fm_lpf; s.fm_hpf_a = fm_ha; s.fm_hpf_b = fm_hb; s.fm_i_prev = fm_ip; s.fm_q_prev = fm_qp;
+    s.fm_sql_avg = fm_avg; s.fm_sql_count = fm_cnt; s.squelched = squelched; s.blocks = blocks;
 }
 
 /* ---- FFT panadapter ---------------------------------------------------------- */

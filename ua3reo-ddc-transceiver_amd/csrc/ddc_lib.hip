@@ -778,6 +778,8 @@ int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t
     if (!spec_iq || !voice_iq || !audio_lr) return fail(ctx, -EINVAL, "null buffer");
     if (n_frames % ddc::kABlock) return fail(ctx, -EINVAL, "n_frames must be a multiple of 192");
     if (n_frames > 0xFFFFFF00u) return fail(ctx, -EINVAL, "n_frames too large");
+    if (((uintptr_t)spec_iq | (uintptr_t)voice_iq | (uintptr_t)audio_lr) % 16)
+        return fail(ctx, -EINVAL, "audio buffers must be 16-byte aligned");
     int rc = audio_all_ready(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
