@@ -80,23 +80,6 @@ struct TxAudioState {
     uint32_t fm_accum;
 };
 
-__device__ __forceinline__ void lattice_step(Lattice &s, int n, const float *k, const float *v, float &x)
-{
-    float fcurr = x, fnext = x, acc = 0.0f, ng[12];
-    for (int i = 0; i < n; i++) {
-        const float gcurr = s.g[i];
-        fnext = fcurr - k[i] * gcurr;
-        const float gnext = fnext * k[i] + gcurr;
-        acc += gnext * v[i];
-        ng[i] = gnext;
-        fcurr = fnext;
-    }
-    acc += fnext * v[n];
-    for (int i = 0; i + 1 < n; i++) s.g[i] = ng[i + 1];
-    s.g[n - 1] = fnext;
-    x = acc;
-}
-
 __device__ __forceinline__ float dc_step(AudioState &s, int slot, float in)
 {
     const float A1 = 0.99951171875f; // 1 - 2^-11
@@ -167,48 +150,6 @@ __device__ inline void agc_block(AudioState &s, float *buf)
         }
     } else
         for (int i = 0; i < kABlock; i++) buf[i] = buf[i] * s.agc_gain;
-}
-
-__device__ inline void fm_block(AudioState &s, float *bi, const float *bq)
-{
-    float first_angle = 0;
-    for (int i = 0; i < kABlock; i++) {
-        const float y = (bq[i] * s.fm_i_prev) - (bi[i] * s.fm_q_prev);
-        const float x = (bi[i] * s.fm_i_prev) + (bq[i] * s.fm_q_prev);
-        const float angle = atan2f(y, x);
-        if (i == 0) first_angle = angle;
-        const float a = s.fm_lpf_prev + (0.05f * (angle - s.fm_lpf_prev));
-        s.fm_lpf_prev = a;
-        s.fm_q_prev = bq[i];
-        s.fm_i_prev = bi[i];
-        if (!s.squelched || !s.p.fm_sql_threshold) {
-            if (s.p.mode == DDC_MODE_WFM)
-                bi[i] = angle / kPiF * 16384.0f;
-            else {
-                const float b = 0.96f * (s.fm_hpf_b + a - s.fm_hpf_a);
-                s.fm_hpf_a = a;
-                s.fm_hpf_b = b;
-                bi[i] = b * 30000.0f;
-            }
-        } else
-            bi[i] = 0;
-    }
-    s.fm_sql_avg = ((1.0f - 0.005f) * s.fm_sql_avg) + (0.005f * sqrtf(fabsf(first_angle)));
-    if (s.fm_sql_count == 0) {
-        if (s.fm_sql_avg > 0.7f) s.fm_sql_avg = 0.7f;
-        const float b = s.fm_sql_avg * 10.0f;
-        const int thr = s.p.fm_sql_threshold;
-        if (!thr) s.squelched = 0;
-        else if (s.squelched) {
-            if (b <= (float)((10 - thr) - 0.3f)) s.squelched = 0;
-        } else {
-            if ((10.0f - thr) > 0.3f) {
-                if (b > (float)((10 - thr) + 0.3f)) s.squelched = 1;
-            } else if (b > (10.0f - (float)thr)) s.squelched = 1;
-        }
-        s.fm_sql_count++; // only ever bumped here, as in the firmware
-        if (s.fm_sql_count >= 50) s.fm_sql_count = 0;
-    }
 }
 
 __device__ inline int dev_strlen(const char *s) { int n = 0; while (s[n]) n++; return n; }
@@ -741,140 +682,193 @@ __device__ __forceinline__ uint32_t f2u_sat(float v)
 
 __constant__ float c_tx_hilbert[2][201]; // [0] = +45 degree (I) taps, [1] = -45 degree (Q) taps
 
-/* arm_fir_f32, 201 taps, one accumulator, taps in ascending order; ext holds the
- * 200 samples before the sub-block followed by its 64 samples */
-__device__ inline void tx_fir_block(const float *taps, float *hist, float *buf)
+/*
+ * processTxAudio for every channel, first half: thread = channel, sequential over
+ * blocks of 192 frames.  mic_lr: [channel][n_frames][2] int16 (left, right).
+ * Everything that is recursion in time runs here: DC blockers (slots 2, 3), the
+ * HPF / LPF lattices (the firmware's shared instances IIR_HPF_I, IIR_LPF_I), the
+ * ALC compressor (one gain per block from the block's peak) and the FM phase
+ * accumulator.  For the modes that end in the +-45 degree FIR pair (SSB, DIGI, AM)
+ * the gain-scaled samples go to xs[channel][200 + n_frames] (the 200 samples the
+ * FIR delay lines held come first) and the second kernel finishes the block; the
+ * other modes (CW, FM, IQ, LOOPBACK, tune) write their output here.
+ */
+__device__ __forceinline__ bool tx_mode_has_fir(int m)
 {
-    float ext[200 + kASub];
-    for (int i = 0; i < 200; i++) ext[i] = hist[i];
-    for (int i = 0; i < kASub; i++) ext[200 + i] = buf[i];
-    for (int t = 0; t < kASub; t++) {
-        float acc = 0.0f;
-        for (int k = 0; k < 201; k++) acc += ext[t + k] * taps[k];
-        buf[t] = acc;
-    }
-    for (int i = 0; i < 200; i++) hist[i] = ext[kASub + i];
+    return m == DDC_MODE_USB || m == DDC_MODE_DIGI_U || m == DDC_MODE_LSB || m == DDC_MODE_DIGI_L || m == DDC_MODE_AM;
 }
 
-/*
- * processTxAudio for every channel: thread = channel, sequential over blocks of
- * 192 frames.  mic_lr: [channel][n_frames][2] int16 (left, right); iq_out:
- * [channel][n_frames][2] int16 (I, Q) as FPGA_fpgadata_sendiq narrows them
- * (fpga.c:403-436); loop_lr: [channel][n_frames][2] int32, the codec output of
- * LOOPBACK mode (zero in every other mode), may be null.  The HPF / LPF lattice
- * instances and DC-blocker slots are the firmware's shared ones (IIR_HPF_I,
- * IIR_LPF_I, slots 2 and 3).
- */
 __global__ __launch_bounds__(64) void ddc_audio_tx(AudioState *__restrict__ states, TxAudioState *__restrict__ txs,
                                                    uint32_t n_ch, const int16_t *__restrict__ mic_lr, uint32_t n_frames,
-                                                   int16_t *__restrict__ iq_out, int32_t *__restrict__ loop_lr)
+                                                   int16_t *__restrict__ iq_out, int32_t *__restrict__ loop_lr,
+                                                   float *__restrict__ xs)
 {
+    __shared__ float blockbuf[64 * kABiPitch];
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
     AudioState &s = states[ch];
     TxAudioState &x = txs[ch];
+    float *bi = &blockbuf[threadIdx.x * kABiPitch];
     const ddc_audio_params p = s.p;
     const int m = p.mode;
     const bool tune = p.tune != 0;
+    const bool fir = tx_mode_has_fir(m) && !tune;
+    const bool lpf = p.filter_width > 0;
     const float amp0 = p.rf_power / 100.0f * 31000.0f; // MAX_TX_AMPLITUDE, settings.h:13
-    Lattice hpf = s.hpf_i, lpf = s.lpf_i;
-    const float *lk = ddc_lpf_k[s.lpf_idx], *lv = ddc_lpf_v[s.lpf_idx];
-    const float *hk = ddc_hpf_k[s.hpf_idx], *hv = ddc_hpf_v[s.hpf_idx];
     const int lpf_n = s.lpf_n;
+    float lk[11], lv[12], hk[11], hv[12], gh[11], gl[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+        lk[i] = ddc_lpf_k[s.lpf_idx][i]; hk[i] = i < 6 ? ddc_hpf_k[s.hpf_idx][i] : 0.0f;
+        gh[i] = s.hpf_i.g[i]; gl[i] = s.lpf_i.g[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lv[i] = ddc_lpf_v[s.lpf_idx][i]; hv[i] = i < 7 ? ddc_hpf_v[s.hpf_idx][i] : 0.0f; }
+    float dx2 = s.dc_x[2], dy2 = s.dc_y[2], dx3 = s.dc_x[3], dy3 = s.dc_y[3];
     float alc = x.alc_gain, fa = x.fm_hpf_a, fb = x.fm_hpf_b, mxa = x.max_amplitude;
+    const float fm_index = x.fm_index;
     uint32_t facc = x.fm_accum;
+    const float A1 = 0.99951171875f;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(mic_lr) + (size_t)ch * n_frames;
     uint32_t *dst = reinterpret_cast<uint32_t *>(iq_out) + (size_t)ch * n_frames;
     int32_t *lp = loop_lr ? loop_lr + (size_t)ch * n_frames * 2 : nullptr;
-    float bi[kABlock], bq[kABlock];
+    float *xrow = xs + (size_t)ch * (200 + (size_t)n_frames);
+    if (fir)
+        for (int i = 0; i < 200; i++) xrow[i] = x.fir_i[i];
     for (uint32_t b0 = 0; b0 + kABlock <= n_frames; b0 += kABlock) {
         float amp = amp0;
-        for (int i = 0; i < kABlock; i++) {
-            if (tune) { bi[i] = amp; bq[i] = amp; continue; }
-            const uint32_t v = src[b0 + i];
-            float fi = dc_step(s, 2, (float)(int16_t)(v & 0xFFFFu));
-            const float fq = dc_step(s, 3, (float)((int32_t)v >> 16));
-            if (m != DDC_MODE_IQ) {
-                lattice_step(hpf, 6, hk, hv, fi);
-                if (p.filter_width > 0) lattice_step(lpf, lpf_n, lk, lv, fi);
-                bi[i] = fi; bq[i] = fi;
-            } else { bi[i] = fi; bq[i] = fq; }
-        }
-        if (m != DDC_MODE_IQ && !tune) {
-            float mx = 0;
+        if (tune) {
+            const uint32_t w = (uint32_t)(uint16_t)(int16_t)f2i_sat(amp);
             for (int i = 0; i < kABlock; i++) {
-                const float a = fabsf(bi[i]);
-                if (a > mx) mx = a;
-            }
-            if (mx == 0.0f) mx = 0.001f;
-            mxa = mx;
-            const float target = amp / mx;
-            if (target > alc) alc += (target - alc) / 500.0f;
-            else alc -= (alc - target) / 500.0f;
-            if (target < alc) alc = target;
-            if (alc < 0.0f) alc = 0.0f;
-            if ((alc * mx) > (amp * 1.1f)) alc = target;
-            if (alc > 500.0f) alc = 500.0f;
-            if (mx < 15.0f) alc = 0.0f;
-            if ((alc > 1.0f) && (m == DDC_MODE_DIGI_L || m == DDC_MODE_DIGI_U || m == DDC_MODE_LOOPBACK)) alc = 1.0f;
-            for (int i = 0; i < kABlock; i++) { bi[i] = bi[i] * alc; bq[i] = bq[i] * alc; }
-            switch (m) {
-            case DDC_MODE_CW_L: case DDC_MODE_CW_U:
-                if (!p.key) amp = 0;
-                for (int i = 0; i < kABlock; i++) { bi[i] = amp; bq[i] = amp; }
-                break;
-            case DDC_MODE_USB: case DDC_MODE_DIGI_U:
-                for (int sb = 0; sb < kABlock / kASub; sb++) {
-                    tx_fir_block(c_tx_hilbert[1], x.fir_q, bi + sb * kASub);
-                    tx_fir_block(c_tx_hilbert[0], x.fir_i, bq + sb * kASub);
-                }
-                break;
-            case DDC_MODE_LSB: case DDC_MODE_DIGI_L: case DDC_MODE_AM:
-                for (int sb = 0; sb < kABlock / kASub; sb++) {
-                    tx_fir_block(c_tx_hilbert[0], x.fir_i, bi + sb * kASub);
-                    tx_fir_block(c_tx_hilbert[1], x.fir_q, bq + sb * kASub);
-                }
-                if (m == DDC_MODE_AM)
-                    for (int i = 0; i < kABlock; i++) {
-                        const float i_am = ((bi[i] - bq[i]) + amp) / 2.0f;
-                        const float q_am = ((bq[i] - bi[i]) - amp) / 2.0f;
-                        bi[i] = i_am; bq[i] = q_am;
-                    }
-                break;
-            case DDC_MODE_NFM: case DDC_MODE_WFM:
-                for (int i = 0; i < kABlock; i++) { // ModulateFM
-                    const float a = bi[i];
-                    fb = 0.95f * (fb + a - fa);
-                    fa = a;
-                    facc = f2u_sat((float)facc + fb) % 48000u;
-                    const float sd = (facc / (float)48000) * kPiF * x.fm_index;
-                    bi[i] = amp * sinf(sd);
-                    bq[i] = amp * cosf(sd);
-                }
-                break;
-            default: break;
-            }
-        }
-        if (p.mute && !tune)
-            for (int i = 0; i < kABlock; i++) { bi[i] = bi[i] * 0; bq[i] = bq[i] * 0; }
-        if (m == DDC_MODE_LOOPBACK && !tune) {
-            const float vol = (float)p.volume / 50.0f;
-            for (int i = 0; i < kABlock; i++) {
-                const int32_t v = f2i_sat(bi[i] * vol);
-                if (lp) { lp[2 * (b0 + i)] = v; lp[2 * (b0 + i) + 1] = v; }
-                dst[b0 + i] = 0;
-            }
-        } else
-            for (int i = 0; i < kABlock; i++) {
-                const uint32_t wi = (uint32_t)(uint16_t)(int16_t)f2i_sat(bi[i]);
-                const uint32_t wq = (uint32_t)(uint16_t)(int16_t)f2i_sat(bq[i]);
-                dst[b0 + i] = wi | (wq << 16);
+                dst[b0 + i] = w | (w << 16);
                 if (lp) { lp[2 * (b0 + i)] = 0; lp[2 * (b0 + i) + 1] = 0; }
             }
+            continue;
+        }
+        float mx = 0;
+        for (int i0 = 0; i0 < kABlock; i0 += 16) {
+            uint4 in4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) in4[k] = reinterpret_cast<const uint4 *>(src + b0 + i0)[k];
+            const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
+                                      in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t v = in[k];
+                float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
+                { const float d = fi - dx2; const float a = A1 * dy2; const float o = d + a; dx2 = fi; dy2 = o; fi = o; }
+                { const float d = fq - dx3; const float a = A1 * dy3; const float o = d + a; dx3 = fq; dy3 = o; fq = o; }
+                if (m == DDC_MODE_IQ) { // raw stereo through the DC blockers
+                    float oi = fi, oq = fq;
+                    if (p.mute) { oi = oi * 0; oq = oq * 0; }
+                    dst[b0 + i0 + k] = (uint32_t)(uint16_t)(int16_t)f2i_sat(oi) | ((uint32_t)(uint16_t)(int16_t)f2i_sat(oq) << 16);
+                    if (lp) { lp[2 * (b0 + i0 + k)] = 0; lp[2 * (b0 + i0 + k) + 1] = 0; }
+                    continue;
+                }
+                fi = lattice_reg<6>(gh, hk, hv, fi);
+                if (lpf) fi = lpf_n == 11 ? lattice_reg<11>(gl, lk, lv, fi) : lattice_reg<7>(gl, lk, lv, fi);
+                const float a = fabsf(fi);
+                if (a > mx) mx = a;
+                bi[i0 + k] = fi;
+            }
+        }
+        if (m == DDC_MODE_IQ) continue;
+        // RF power control / compressor, audio_processor.c:112-145
+        if (mx == 0.0f) mx = 0.001f;
+        mxa = mx;
+        const float target = amp / mx;
+        if (target > alc) alc += (target - alc) / 500.0f;
+        else alc -= (alc - target) / 500.0f;
+        if (target < alc) alc = target;
+        if (alc < 0.0f) alc = 0.0f;
+        if ((alc * mx) > (amp * 1.1f)) alc = target;
+        if (alc > 500.0f) alc = 500.0f;
+        if (mx < 15.0f) alc = 0.0f;
+        if ((alc > 1.0f) && (m == DDC_MODE_DIGI_L || m == DDC_MODE_DIGI_U || m == DDC_MODE_LOOPBACK)) alc = 1.0f;
+        if (fir) {
+            for (int i = 0; i < kABlock; i++) xrow[200 + b0 + i] = bi[i] * alc;
+            continue;
+        }
+        const bool cw = m == DDC_MODE_CW_L || m == DDC_MODE_CW_U;
+        const bool fmm = m == DDC_MODE_NFM || m == DDC_MODE_WFM;
+        if (cw && !p.key) amp = 0;
+        const float vol = (float)p.volume / 50.0f;
+        for (int i = 0; i < kABlock; i++) {
+            float oi = bi[i] * alc, oq = oi;
+            if (cw) { oi = amp; oq = amp; }
+            else if (fmm) { // ModulateFM, audio_processor.c:590-619
+                fb = 0.95f * (fb + oi - fa);
+                fa = oi;
+                facc = f2u_sat((float)facc + fb) % 48000u;
+                const float sd = (facc / (float)48000) * kPiF * fm_index;
+                oi = amp * sinf(sd);
+                oq = amp * cosf(sd);
+            }
+            if (p.mute) { oi = oi * 0; oq = oq * 0; }
+            if (m == DDC_MODE_LOOPBACK) {
+                const int32_t v = f2i_sat(oi * vol);
+                if (lp) { lp[2 * (b0 + i)] = v; lp[2 * (b0 + i) + 1] = v; }
+                dst[b0 + i] = 0;
+            } else {
+                dst[b0 + i] = (uint32_t)(uint16_t)(int16_t)f2i_sat(oi) | ((uint32_t)(uint16_t)(int16_t)f2i_sat(oq) << 16);
+                if (lp) { lp[2 * (b0 + i)] = 0; lp[2 * (b0 + i) + 1] = 0; }
+            }
+        }
     }
-    s.hpf_i = hpf;
-    s.lpf_i = lpf;
+    if (fir && n_frames >= kABlock) { // what the FIR delay lines hold after the call
+        const uint32_t done = n_frames / kABlock * kABlock;
+        for (int i = 0; i < 200; i++) { const float v = xrow[done + i]; x.fir_i[i] = v; x.fir_q[i] = v; }
+    }
+#pragma unroll
+    for (int i = 0; i < 11; i++) { s.hpf_i.g[i] = gh[i]; s.lpf_i.g[i] = gl[i]; }
+    s.dc_x[2] = dx2; s.dc_y[2] = dy2; s.dc_x[3] = dx3; s.dc_y[3] = dy3;
     x.alc_gain = alc; x.fm_hpf_a = fa; x.fm_hpf_b = fb; x.fm_accum = facc; x.max_amplitude = mxa;
+}
+
+/*
+ * processTxAudio, second half, for the channels in an SSB / DIGI / AM mode: the
+ * +-45 degree Hilbert pair (arm_fir_f32, 201 taps each, audio_filters.c:41-42) over
+ * the gain-scaled samples, then sideband selection / AM carrier, mute and the
+ * narrowing to the 16-bit bus words.  One thread per output frame; a workgroup
+ * covers 256 consecutive frames of one channel from 456 staged samples.  Every
+ * output is one accumulator fed tap by tap in ascending order, as the CMSIS
+ * routine does it, so the result does not depend on the parallel split.
+ */
+__global__ __launch_bounds__(256) void ddc_audio_tx_fir(const AudioState *__restrict__ states, uint32_t tiles,
+                                                        const float *__restrict__ xs, uint32_t n_frames,
+                                                        int16_t *__restrict__ iq_out, int32_t *__restrict__ loop_lr)
+{
+    __shared__ float win[256 + 200];
+    const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * 256u, t = threadIdx.x;
+    const ddc_audio_params p = states[ch].p;
+    const int m = p.mode;
+    if (!tx_mode_has_fir(m) || p.tune) return; // uniform over the workgroup
+    const uint32_t done = n_frames / kABlock * kABlock;
+    const float *xrow = xs + (size_t)ch * (200 + (size_t)n_frames);
+    for (uint32_t j = t; j < 456; j += 256) win[j] = n0 + j < 200 + done ? xrow[n0 + j] : 0.0f;
+    __syncthreads();
+    const uint32_t n = n0 + t;
+    if (n >= done) return;
+    float ai = 0.0f, aq = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 201; k++) {
+        const float v = win[t + k];
+        ai += v * c_tx_hilbert[0][k];
+        aq += v * c_tx_hilbert[1][k];
+    }
+    float oi, oq;
+    if (m == DDC_MODE_USB || m == DDC_MODE_DIGI_U) { oi = aq; oq = ai; }
+    else { oi = ai; oq = aq; }
+    if (m == DDC_MODE_AM) {
+        const float amp = p.rf_power / 100.0f * 31000.0f;
+        const float i_am = ((oi - oq) + amp) / 2.0f;
+        const float q_am = ((oq - oi) - amp) / 2.0f;
+        oi = i_am; oq = q_am;
+    }
+    if (p.mute) { oi = oi * 0; oq = oq * 0; }
+    reinterpret_cast<uint32_t *>(iq_out)[(size_t)ch * n_frames + n] =
+        (uint32_t)(uint16_t)(int16_t)f2i_sat(oi) | ((uint32_t)(uint16_t)(int16_t)f2i_sat(oq) << 16);
+    if (loop_lr) { loop_lr[((size_t)ch * n_frames + n) * 2] = 0; loop_lr[((size_t)ch * n_frames + n) * 2 + 1] = 0; }
 }
 
 /* Operator settings that do not select a filter, changed without touching the

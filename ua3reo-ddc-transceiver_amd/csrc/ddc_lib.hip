@@ -51,6 +51,8 @@ struct ddc_ctx {
     ddc::AudioState *d_audio = nullptr;
     ddc::ZoomState *d_zoom = nullptr;
     ddc::TxAudioState *d_audio_tx = nullptr;
+    float *d_tx_xs = nullptr;          // [ch][200 + frames] gain-scaled TX audio ahead of the Hilbert FIR pair
+    size_t tx_xs_cap = 0;              // frames per channel it holds
     uint32_t fft_zoom_all = 1;         // common zoom factor of all channels (0 = mixed)
     std::vector<uint8_t> audio_ready;  // per channel: ddc_audio_configure seen
     std::vector<uint8_t> zoom_of;      // per channel: configured FFT zoom
@@ -311,7 +313,7 @@ void ddc_destroy(ddc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
-                     ctx->d_out, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
+                     ctx->d_out, ctx->d_tx_xs, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
                      ctx->d_stage[2] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -886,12 +888,23 @@ int ddc_audio_tx_process_dev(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frame
     if (!mic_lr || !iq48k) return fail(ctx, -EINVAL, "null buffer");
     if (n_frames % ddc::kABlock) return fail(ctx, -EINVAL, "n_frames must be a multiple of 192");
     if (n_frames > 0xFFFFFF00u) return fail(ctx, -EINVAL, "n_frames too large");
+    if ((uintptr_t)mic_lr % 16) return fail(ctx, -EINVAL, "mic_lr must be 16-byte aligned");
     int rc = audio_all_ready(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const uint32_t nch = ctx->cfg.n_channels;
+    if (n_frames > ctx->tx_xs_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_tx_xs) (void)hipFree(ctx->d_tx_xs);
+        ctx->d_tx_xs = nullptr; ctx->tx_xs_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_tx_xs, (size_t)nch * (200 + n_frames) * sizeof(float)));
+        ctx->tx_xs_cap = n_frames;
+    }
     hipLaunchKernelGGL(ddc::ddc_audio_tx, dim3((nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, ctx->d_audio_tx,
-                       nch, mic_lr, (uint32_t)n_frames, iq48k, loop_lr);
+                       nch, mic_lr, (uint32_t)n_frames, iq48k, loop_lr, ctx->d_tx_xs);
+    const uint32_t ftiles = (uint32_t)((n_frames + 255) / 256);
+    hipLaunchKernelGGL(ddc::ddc_audio_tx_fir, dim3(nch * ftiles), dim3(256), 0, ctx->stream, ctx->d_audio, ftiles,
+                       ctx->d_tx_xs, (uint32_t)n_frames, iq48k, loop_lr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
