@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""BASELINE config 2 shape: one channel, one second of ADC (~65 MS) through the whole RX
+chain to 48 kHz-class audio (USB, 2.7 kHz LPF, 300 Hz HPF, AGC on, DNR off).  Prints the
+time of the DDC half and of the audio half."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ua3reo-ddc-transceiver_amd"))
+import torch  # noqa: E402
+import ua3reo_ddc as u  # noqa: E402
+from bench import synth_rows  # noqa: E402
+
+S = 347 * 192 * 1024  # 68.2 M samples: a whole number of 192-frame audio blocks
+dev = torch.device("cuda", 0)
+adc = synth_rows(1, S, 0, dev, 0x5EED0000)
+nf = S // 1024
+spec = torch.zeros((1, nf, 2), dtype=torch.int16, device=dev)
+voice = torch.zeros_like(spec)
+audio = torch.zeros((1, nf, 2), dtype=torch.int32, device=dev)
+d = u.Ddc(1)
+d.tune_hz(0, 1000000)
+d.audio_configure(u.audio_params(mode="USB", filter_width=2700, hpf_pass=300, agc=1, dnr=0))
+torch.cuda.synchronize()
+for it in range(3):
+    t0 = time.perf_counter()
+    d.rx_process_dev(adc.data_ptr(), S // 2 * 3, S, spec.data_ptr(), voice.data_ptr())
+    d.sync()
+    t1 = time.perf_counter()
+    d.audio_rx_process_dev(spec.data_ptr(), voice.data_ptr(), nf, audio.data_ptr())
+    d.sync()
+    t2 = time.perf_counter()
+print("config-2 shape: 1 channel x %d samples: DDC %.3f ms (%.0f MS/s), audio %.3f ms for %d frames (%.1fx real time)" % (
+    S, (t1 - t0) * 1e3, S / (t1 - t0) / 1e6, (t2 - t1) * 1e3, nf, nf / 48000.0 / (t2 - t1)))
+print("audio peak", int(audio.abs().max()))
