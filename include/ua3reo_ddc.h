@@ -191,6 +191,13 @@ typedef struct ddc_audio_status {
  * Must be called before the first audio / FFT call.  -EINVAL when filter_width or
  * hpf_pass name no table of the firmware. */
 int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p);
+/* The waterfall of one channel (wtf_buffer, fft.c:28, :353-376): the colour rows of
+ * the last 50 frames, newest first, [50][256] RGB565 (host pointer; waits for the
+ * stream).  ddc_fft_move_waterfall is FFT_moveWaterfall (fft.c:453-503): after a
+ * retune by freq_diff_hz the picture and the smoothed bins move sideways by
+ * (freq_diff_hz / 187) * fft_zoom pixels, the bins in the firmware's in-place order. */
+int ddc_fft_get_waterfall(ddc_ctx *ctx, int32_t channel, uint16_t *rows);
+int ddc_fft_move_waterfall(ddc_ctx *ctx, int32_t channel, int32_t freq_diff_hz);
 /* Changes the settings that select no filter (agc, dnr, notch on/off, mute,
  * cw_decoder, fm_sql_threshold, volume, iq_swap, fft_averaging, rf_power, tune, key,
  * agc_speed, rf_gain) and keeps all running state, as the firmware does when it

@@ -133,6 +133,7 @@ typedef struct {
     /* FFT, fft.c */
     float fft_mean[FFT_PRINT], fft_max_value;
     uint16_t fft_max_errors;
+    uint16_t wtf[50][FFT_PRINT]; /* wtf_buffer, fft.c:28: row 0 is the newest */
     /* zoom FFT (fft.c:44-209,236-261): 4-stage DF1 biquad, 4-tap decimator, sliding buffer */
     float zoom_c[20], zoom_fir[4];
     float zoom_bq_i[16], zoom_bq_q[16];       /* per stage x1,x2,y1,y2 */
@@ -788,5 +789,44 @@ void orc_fft_frame(orc_audio_t *s, const int16_t *spec_iq, float *bins, uint16_t
         else c = fft_color((uint8_t)h);
         row[nx] = c;
         heights[nx] = (uint8_t)h;
+    }
+    /* FFT_printFFT scrolls the waterfall down by one row and puts the new one on top (fft.c:353-376) */
+    memmove(s->wtf[1], s->wtf[0], sizeof(uint16_t) * 49 * FFT_PRINT);
+    memcpy(s->wtf[0], row, sizeof(uint16_t) * FFT_PRINT);
+}
+
+void orc_fft_get_waterfall(const orc_audio_t *s, uint16_t *out) { memcpy(out, s->wtf, sizeof s->wtf); }
+
+/* FFT_moveWaterfall (fft.c:453-503): on a retune by freq_diff Hz the picture moves
+ * sideways by (freq_diff / 187) * zoom pixels; the smoothed bins are moved in place
+ * in the same loop, in their own (unshifted) bin order, exactly as written. */
+void orc_fft_move_waterfall(orc_audio_t *s, int16_t freq_diff)
+{
+    const int zoom = s->p.fft_zoom > 1 ? s->p.fft_zoom : 1;
+    freq_diff = (int16_t)((freq_diff / (48000 / FFT_PRINT)) * zoom);
+    for (int y = 0; y < 50; y++) {
+        if (freq_diff > 0) {
+            for (int x = 0; x < FFT_PRINT; x++) {
+                const int new_x = x + freq_diff;
+                if (y == 0) {
+                    int fx = new_x;
+                    if (fx >= FFT_PRINT) fx -= FFT_PRINT;
+                    if (fx >= 0 && fx < FFT_PRINT) s->fft_mean[x] = s->fft_mean[fx];
+                }
+                if (new_x < 0 || new_x >= FFT_PRINT) { s->wtf[y][x] = 0; continue; }
+                s->wtf[y][x] = s->wtf[y][new_x];
+            }
+        } else if (freq_diff < 0) {
+            for (int x = FFT_PRINT - 1; x >= 0; x--) {
+                const int new_x = x + freq_diff;
+                if (y == 0) {
+                    int fx = new_x;
+                    if (fx < 0) fx += FFT_PRINT;
+                    if (fx >= 0 && fx < FFT_PRINT) s->fft_mean[x] = s->fft_mean[fx];
+                }
+                if (new_x < 0) { s->wtf[y][x] = 0; continue; }
+                s->wtf[y][x] = s->wtf[y][new_x];
+            }
+        }
     }
 }

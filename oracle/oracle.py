@@ -370,6 +370,14 @@ class Audio:
         return {"smeter_max": mx.value, "smeter_min": mn.value, "agc_gain": g.value,
                 "cw_text": text.value.decode("ascii", "replace"), "cw_wpm": wpm.value, "squelched": bool(sq.value)}
 
+    def waterfall(self):
+        out = np.zeros((50, 256), np.uint16)
+        lib().orc_fft_get_waterfall(self.buf, _p(out))
+        return out
+
+    def move_waterfall(self, freq_diff):
+        lib().orc_fft_move_waterfall(self.buf, C.c_int16(int(freq_diff)))
+
     def tx(self, mic_lr):
         """processTxAudio over n frames (n % 192 == 0): returns (iq int16 [n][2], loopback int32 [n][2])."""
         mic = np.ascontiguousarray(mic_lr, dtype=np.int16).reshape(-1, 2)

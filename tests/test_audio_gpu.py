@@ -290,3 +290,34 @@ def test_full_chain_adc_to_audio(ddc, orc):
     assert np.array_equal(iq[0], wiq)
     dac = d.tx_process(iq[:, :8])
     assert np.array_equal(dac[0], orc.TxChain(phi).run(wiq[:8]))
+
+
+def test_waterfall_and_retune(ddc, orc):
+    frames = 57
+    n = 512 * frames
+    r = np.random.default_rng(23)
+    spec = np.stack([sig.quantise(sig.tone_iq(n, 6000.0, 500.0) + r.normal(0, 20, (n, 2))),
+                     sig.noisy_two_tone(n, 51, amp=1500.0)])
+    cases = [dict(fft_averaging=2, fft_zoom=2), dict(fft_averaging=3, fft_zoom=2)]
+    d = ddc.Ddc(2)
+    oracles = []
+    for c, kw in enumerate(cases):
+        d.audio_configure(ddc.audio_params(**kw), c)
+        oracles.append(orc.Audio(orc.audio_params(**kw)))
+    # three calls of different length, a retune in between
+    cuts = [0, 512 * 3, 512 * 55, n]
+    for k in range(3):
+        d.fft_process(spec[:, cuts[k]:cuts[k + 1]])
+        for c in range(2):
+            for f in range(cuts[k] // 512, cuts[k + 1] // 512):
+                oracles[c].fft(spec[c, 512 * f:512 * (f + 1)])
+        if k == 1:
+            for c, hz in enumerate((1000, -2500)):
+                d.fft_move_waterfall(c, hz)
+                oracles[c].move_waterfall(hz)
+    for c in range(2):
+        got, want = d.fft_waterfall(c), oracles[c].waterfall()
+        assert (got != want).sum() <= 0.002 * got.size, "channel %d" % c
+        assert want.any()
+    with pytest.raises(ddc.DdcError):
+        d.fft_move_waterfall(0, 40000)

@@ -395,3 +395,26 @@ def test_fft_zoom_spreads_the_spectrum(orc, zoom):
     for k in range(frames):
         bins2, _, _ = b.fft(y[512 * k:512 * (k + 1)])
     assert bins2.max() < 0.05 * bins.max()
+
+
+# ---- waterfall -------------------------------------------------------------------
+
+def test_waterfall_scrolls_and_moves(orc):
+    a = orc.Audio(orc.audio_params(fft_averaging=1))
+    x = sig.quantise(sig.tone_iq(512 * 60, 6000.0, 500.0))
+    rows = []
+    for f in range(60):
+        _, row, _ = a.fft(x[512 * f:512 * (f + 1)])
+        rows.append(row)
+    w = a.waterfall()
+    for y in range(50):  # newest first, 50 rows deep
+        assert np.array_equal(w[y], rows[59 - y])
+    # retune up by 1 kHz: 1000 / 187 = 5 pixels to the left, zero fill on the right (fft.c:453-503)
+    a.move_waterfall(1000)
+    w2 = a.waterfall()
+    assert np.array_equal(w2[:, :251], w[:, 5:]) and not w2[:, 251:].any()
+    a.move_waterfall(-1000)
+    w3 = a.waterfall()
+    assert np.array_equal(w3[:, 5:251], w[:, 5:251]) and not w3[:, :5].any()
+    a.move_waterfall(100)  # less than one pixel: nothing moves
+    assert np.array_equal(a.waterfall(), w3)

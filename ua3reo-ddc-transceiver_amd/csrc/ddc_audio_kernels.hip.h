@@ -615,7 +615,7 @@ __device__ inline uint16_t fft_color(int height)
  * the over-range count that feeds the next frame's auto-level. */
 __global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ states, const float *__restrict__ mags,
                                                      uint32_t frames_per_ch, float *__restrict__ bins,
-                                                     uint16_t *__restrict__ rows)
+                                                     uint16_t *__restrict__ rows, uint16_t *__restrict__ wtf)
 {
     __shared__ float red[256];
     __shared__ uint32_t errs;
@@ -662,13 +662,43 @@ __global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ st
         uint16_t c;
         if (h > 29) { c = 0xF800; atomicAdd(&errs, 1u); }
         else c = fft_color(h);
-        if (rows) rows[fr * 256 + nx] = c;
+        rows[fr * 256 + nx] = c;
         __syncthreads();
         max_errors = errs;
         __syncthreads();
     }
     s.fft_mean[x] = mean;
     if (x == 0) { s.fft_max_value = max_value; s.fft_max_errors = max_errors; }
+    // waterfall (wtf_buffer, fft.c:353-376): every frame scrolls the picture down by one
+    // row and lands on top; after F frames the old rows sit F lower
+    __syncthreads();
+    const uint32_t F = frames_per_ch < 50u ? frames_per_ch : 50u;
+    uint16_t *w = wtf + (size_t)ch * 50 * 256;
+    for (int y = 49; y >= (int)F; y--) w[y * 256 + x] = w[(y - (int)F) * 256 + x];
+    for (uint32_t y = 0; y < F; y++) w[y * 256 + x] = rows[((size_t)ch * frames_per_ch + (frames_per_ch - 1 - y)) * 256 + x];
+}
+
+/* FFT_moveWaterfall (fft.c:453-503): on a retune the waterfall moves sideways by
+ * `shift` pixels (zero fill) and the smoothed bins are moved in place in the same
+ * loop order as the firmware's, which is not a clean rotation.  One workgroup;
+ * thread y < 50 walks row y, thread 50 the bins. */
+__global__ void ddc_fft_move_waterfall_k(AudioState *__restrict__ states, uint16_t *__restrict__ wtf, uint32_t ch, int shift)
+{
+    const int y = threadIdx.x;
+    if (shift == 0) return;
+    if (y < 50) {
+        uint16_t *row = wtf + ((size_t)ch * 50 + y) * 256;
+        if (shift > 0)
+            for (int x = 0; x < 256; x++) { const int nx = x + shift; row[x] = nx >= 256 ? (uint16_t)0 : row[nx]; }
+        else
+            for (int x = 255; x >= 0; x--) { const int nx = x + shift; row[x] = nx < 0 ? (uint16_t)0 : row[nx]; }
+    } else if (y == 50) {
+        float *mean = states[ch].fft_mean;
+        if (shift > 0)
+            for (int x = 0; x < 256; x++) { int fx = x + shift; if (fx >= 256) fx -= 256; if (fx >= 0 && fx < 256) mean[x] = mean[fx]; }
+        else
+            for (int x = 255; x >= 0; x--) { int fx = x + shift; if (fx < 0) fx += 256; if (fx >= 0 && fx < 256) mean[x] = mean[fx]; }
+    }
 }
 
 /* ---- TX audio -------------------------------------------------------------------- */

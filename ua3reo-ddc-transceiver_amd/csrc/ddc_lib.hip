@@ -59,6 +59,8 @@ struct ddc_ctx {
     std::vector<ddc_audio_params> audio_cfg; // per channel: what ddc_audio_configure was given
     float2 *d_fft_work = nullptr;      // [ch][n][2] prefiltered SPEC
     float *d_fft_mag = nullptr;        // [ch][frames][256]
+    uint16_t *d_fft_rows = nullptr;    // [ch][frames][256] colour rows when the caller wants none
+    uint16_t *d_wtf = nullptr;         // [ch][50][256] waterfall, row 0 newest
     size_t fft_cap = 0;                // frames per channel d_fft_mag holds
     size_t fft_work_cap = 0;           // float2 per channel d_fft_work holds
     void *d_stage[3] = {nullptr, nullptr, nullptr}; // host-pointer entry points
@@ -277,6 +279,8 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     ctx->audio_cfg.assign(nch, ddc_audio_params{});
     CREATE_TRY(hipMalloc(&ctx->d_audio, nch * sizeof(ddc::AudioState)));
     CREATE_TRY(hipMemsetAsync(ctx->d_audio, 0, nch * sizeof(ddc::AudioState), ctx->stream));
+    CREATE_TRY(hipMalloc(&ctx->d_wtf, nch * 50 * 256 * sizeof(uint16_t)));
+    CREATE_TRY(hipMemsetAsync(ctx->d_wtf, 0, nch * 50 * 256 * sizeof(uint16_t), ctx->stream));
     CREATE_TRY(hipMalloc(&ctx->d_zoom, nch * sizeof(ddc::ZoomState)));
     CREATE_TRY(hipMemsetAsync(ctx->d_zoom, 0, nch * sizeof(ddc::ZoomState), ctx->stream));
     CREATE_TRY(hipMalloc(&ctx->d_audio_tx, nch * sizeof(ddc::TxAudioState)));
@@ -313,7 +317,7 @@ void ddc_destroy(ddc_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
-                     ctx->d_out, ctx->d_tx_xs, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
+                     ctx->d_out, ctx->d_tx_xs, ctx->d_fft_rows, ctx->d_wtf, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
                      ctx->d_stage[2] };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -737,6 +741,7 @@ int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p
         std::vector<ddc::TxAudioState> all(hi - lo, ts);
         HIP_TRY(ctx, hipMemcpy(ctx->d_audio_tx + lo, all.data(), all.size() * sizeof ts, hipMemcpyHostToDevice));
     }
+    HIP_TRY(ctx, hipMemset(ctx->d_wtf + lo * 50 * 256, 0, (hi - lo) * 50 * 256 * sizeof(uint16_t)));
     for (size_t c = lo; c < hi; c++) { ctx->audio_ready[c] = 1; ctx->zoom_of[c] = (uint8_t)zs.zoom; ctx->audio_cfg[c] = *p; }
     ctx->fft_zoom_all = ctx->zoom_of[0];
     for (uint8_t zv : ctx->zoom_of) if (zv != ctx->zoom_of[0]) ctx->fft_zoom_all = 0;
@@ -845,9 +850,11 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_fft_work) (void)hipFree(ctx->d_fft_work);
         if (ctx->d_fft_mag) (void)hipFree(ctx->d_fft_mag);
-        ctx->d_fft_work = nullptr; ctx->d_fft_mag = nullptr; ctx->fft_cap = 0; ctx->fft_work_cap = 0;
+        if (ctx->d_fft_rows) (void)hipFree(ctx->d_fft_rows);
+        ctx->d_fft_work = nullptr; ctx->d_fft_mag = nullptr; ctx->d_fft_rows = nullptr; ctx->fft_cap = 0; ctx->fft_work_cap = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->d_fft_work, nch * pitch * sizeof(float2)));
         HIP_TRY(ctx, hipMalloc(&ctx->d_fft_mag, nch * fpc * 256 * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_fft_rows, nch * fpc * 256 * sizeof(uint16_t)));
         ctx->fft_cap = fpc;
         ctx->fft_work_cap = pitch;
     }
@@ -856,7 +863,7 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
     hipLaunchKernelGGL(ddc::ddc_fft_frames, dim3((unsigned)(nch * fpc)), dim3(64), 0, ctx->stream, ctx->d_fft_work,
                        (uint32_t)fpc, (uint32_t)pitch, zw, ctx->d_fft_mag);
     hipLaunchKernelGGL(ddc::ddc_fft_level, dim3((unsigned)nch), dim3(256), 0, ctx->stream, ctx->d_audio, ctx->d_fft_mag,
-                       (uint32_t)fpc, bins, rows);
+                       (uint32_t)fpc, bins, rows ? rows : ctx->d_fft_rows, ctx->d_wtf);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
@@ -925,6 +932,33 @@ int ddc_audio_tx_process(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, i
     HIP_TRY(ctx, hipMemcpyAsync(iq48k, ctx->d_stage[1], b4, hipMemcpyDeviceToHost, ctx->stream));
     if (loop_lr) HIP_TRY(ctx, hipMemcpyAsync(loop_lr, ctx->d_stage[2], b4 * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_fft_get_waterfall(ddc_ctx *ctx, int32_t channel, uint16_t *rows)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0 || !rows) return fail(ctx, -EINVAL, "ddc_fft_get_waterfall needs one channel and an output");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(rows, ctx->d_wtf + (size_t)channel * 50 * 256, 50 * 256 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ddc_fft_move_waterfall(ddc_ctx *ctx, int32_t channel, int32_t freq_diff_hz)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0) return fail(ctx, -EINVAL, "ddc_fft_move_waterfall needs one channel");
+    if (!ctx->audio_ready[channel]) return fail(ctx, -EINVAL, "ddc_audio_configure has not been called for this channel");
+    if (freq_diff_hz < -32768 || freq_diff_hz > 32767) return fail(ctx, -EINVAL, "freq_diff_hz is an int16 in the firmware");
+    // (freq_diff / FFT_HZ_IN_PIXEL) * TRX.FFT_Zoom, fft.c:457, in the firmware's integer arithmetic
+    const int shift = (int)(int16_t)((freq_diff_hz / (48000 / 256)) * (int)ctx->zoom_of[channel]);
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(ddc::ddc_fft_move_waterfall_k, dim3(1), dim3(64), 0, ctx->stream, ctx->d_audio, ctx->d_wtf,
+                       (uint32_t)channel, shift);
+    HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 
@@ -1042,7 +1076,7 @@ std::vector<StateSeg> state_segments(ddc_ctx *ctx)
         { ctx->tx.d_acc, n * 4 }, { ctx->tx.d_hist_x, n * ddc::kTxXHist * 4 }, { ctx->tx.d_hist_y, n * ddc::kTxYHist * 4 },
         { ctx->d_adc_min, n * 4 }, { ctx->d_adc_max, n * 4 },
         { ctx->d_audio, n * sizeof(ddc::AudioState) }, { ctx->d_zoom, n * sizeof(ddc::ZoomState) },
-        { ctx->d_audio_tx, n * sizeof(ddc::TxAudioState) },
+        { ctx->d_audio_tx, n * sizeof(ddc::TxAudioState) }, { ctx->d_wtf, n * 50 * 256 * sizeof(uint16_t) },
     };
 }
 } // namespace

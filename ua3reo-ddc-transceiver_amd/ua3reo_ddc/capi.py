@@ -106,6 +106,8 @@ def lib():
     L.ddc_state_restore.argtypes = [vp, vp, sz]
     L.ddc_audio_configure.argtypes = [vp, i32, vp]
     L.ddc_audio_update.argtypes = [vp, i32, vp]
+    L.ddc_fft_get_waterfall.argtypes = [vp, i32, vp]
+    L.ddc_fft_move_waterfall.argtypes = [vp, i32, i32]
     L.ddc_audio_stage.argtypes = [vp, i32, C.c_int, C.c_int, vp, C.c_int]
     L.ddc_audio_rx_process_dev.argtypes = [vp, vp, vp, sz, vp]
     L.ddc_audio_rx_process.argtypes = [vp, vp, vp, sz, vp]
@@ -301,6 +303,14 @@ class Ddc:
         rows = np.zeros((self.n_channels, nf, 256), np.uint16)
         self._check(self._L.ddc_fft_process(self._h, _np_ptr(s), s.shape[1], _np_ptr(bins), _np_ptr(rows)))
         return bins, rows
+
+    def fft_waterfall(self, channel):
+        out = np.zeros((50, 256), np.uint16)
+        self._check(self._L.ddc_fft_get_waterfall(self._h, channel, _np_ptr(out)))
+        return out
+
+    def fft_move_waterfall(self, channel, freq_diff_hz):
+        self._check(self._L.ddc_fft_move_waterfall(self._h, channel, int(freq_diff_hz)))
 
     def fft_process_dev(self, spec_ptr, n_frames, bins_ptr, rows_ptr):
         self._check(self._L.ddc_fft_process_dev(self._h, spec_ptr, n_frames, bins_ptr, rows_ptr))
