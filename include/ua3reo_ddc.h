@@ -243,6 +243,10 @@ int ddc_audio_tx_process(ddc_ctx *ctx, const int16_t *mic_lr, size_t n_frames, i
  * in place; the call waits for the result. */
 enum ddc_audio_stage_id { DDC_STAGE_DC = 0, DDC_STAGE_AGC = 1, DDC_STAGE_DNR = 2, DDC_STAGE_CW = 3 };
 int ddc_audio_stage(ddc_ctx *ctx, int32_t channel, int stage, int arg, float *buf, int n);
+/* The S-meter reading the firmware takes every 100 ms (stm32f4xx_it.c:398-411):
+ * peak-to-peak of the audio samples since the last reading -> dBm at the antenna
+ * input (TRX_RX_dBm), with the firmware's log10f_fast; clears the extremes. */
+int ddc_audio_smeter_dbm(ddc_ctx *ctx, int32_t channel, float *dbm);
 /* S-meter extremes, AGC / ALC gain, CW decoder text (waits for the ctx stream). */
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
 

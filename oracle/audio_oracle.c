@@ -649,6 +649,39 @@ void orc_audio_tx_run(orc_audio_t *s, const int16_t *mic_lr, size_t n_frames, in
 
 float orc_audio_alc_gain(const orc_audio_t *s) { return s->alc_gain; }
 
+/* S-meter, stm32f4xx_it.c:398-411 (every 100 ms): peak-to-peak of the audio samples
+ * since the last reading -> volts at the ADC -> dBm into 50 ohm, then the extremes
+ * are cleared.  log10f_fast is the firmware's own cubic (functions.c:247-260). */
+static float log10f_fast(float X)
+{
+    float Y, F;
+    int E;
+    F = frexpf(fabsf(X), &E);
+    Y = 1.23149591368684f;
+    Y *= F;
+    Y += -4.11852516267426f;
+    Y *= F;
+    Y += 6.02197014179219f;
+    Y *= F;
+    Y += -3.13396450166353f;
+    Y += E;
+    return (Y * 0.3010299956639812f);
+}
+
+float orc_audio_smeter_dbm(orc_audio_t *s)
+{
+    float vpp = (s->smeter_max / (float)s->p.rf_gain) - (s->smeter_min / (float)s->p.rf_gain);
+    for (int i = 0; i < (16 - 12); i++) vpp = vpp / 2;
+    const float adc_vpp = vpp * 1.0f / ((float)pow(2.0, 12) - 1);
+    const float vrms = adc_vpp * 0.3535f;
+    float rf_in = (vrms / 4) * 0.2f;
+    if (rf_in < 0.0000001f) rf_in = 0.0000001f;
+    const float dbm = 10 * log10f_fast((rf_in * rf_in) / (50.0f * 0.001f));
+    s->smeter_max = 0;
+    s->smeter_min = 0;
+    return dbm;
+}
+
 /* ---- FFT panadapter ---------------------------------------------------------- */
 static void fft512(double *re, double *im)
 {

@@ -370,6 +370,11 @@ class Audio:
         return {"smeter_max": mx.value, "smeter_min": mn.value, "agc_gain": g.value,
                 "cw_text": text.value.decode("ascii", "replace"), "cw_wpm": wpm.value, "squelched": bool(sq.value)}
 
+    def smeter_dbm(self):
+        f = lib().orc_audio_smeter_dbm
+        f.restype = C.c_float
+        return float(f(self.buf))
+
     def waterfall(self):
         out = np.zeros((50, 256), np.uint16)
         lib().orc_fft_get_waterfall(self.buf, _p(out))

@@ -321,3 +321,18 @@ def test_waterfall_and_retune(ddc, orc):
         assert want.any()
     with pytest.raises(ddc.DdcError):
         d.fft_move_waterfall(0, 40000)
+
+
+def test_smeter_dbm_matches_oracle(ddc, orc):
+    n = 192 * 6
+    spec, voice = make_inputs(2, n, 700)
+    d = ddc.Ddc(2)
+    kws = [dict(mode="USB", rf_gain=20.0), dict(mode="AM", rf_gain=3.0)]
+    for c, kw in enumerate(kws):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    d.audio_rx_process(spec, voice)
+    for c, kw in enumerate(kws):
+        a = orc.Audio(orc.audio_params(**kw))
+        a.rx(spec[c], voice[c])
+        assert d.smeter_dbm(c) == a.smeter_dbm()
+        assert d.audio_status(c)["smeter_max"] == 0.0

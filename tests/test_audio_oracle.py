@@ -418,3 +418,18 @@ def test_waterfall_scrolls_and_moves(orc):
     assert np.array_equal(w3[:, 5:251], w[:, 5:251]) and not w3[:, :5].any()
     a.move_waterfall(100)  # less than one pixel: nothing moves
     assert np.array_equal(a.waterfall(), w3)
+
+
+def test_smeter_dbm(orc):
+    # S9 on HF is -73 dBm = 50 uV rms at the antenna; through the firmware's chain
+    # (x0.2 calibration, 1:4 transformer, 1 V full scale, 12 bit) that is a peak-to-peak
+    # of about 11.6 LSB of the 12-bit ADC = 185 LSB of the 16-bit bus samples
+    a = orc.Audio(orc.audio_params(mode="IQ", rf_gain=10.0, volume=100))
+    n = 192 * 4
+    t = np.arange(n)
+    x = sig.quantise(92.6 * np.stack([np.cos(2 * np.pi * 0.01 * t), np.sin(2 * np.pi * 0.01 * t)], axis=1))
+    a.rx(x, np.zeros_like(x))
+    dbm = a.smeter_dbm()
+    assert abs(dbm - (-73.0)) < 1.0
+    assert a.status()["smeter_max"] == 0.0 and a.status()["smeter_min"] == 0.0
+    assert a.smeter_dbm() == pytest.approx(-126.99, abs=0.1)  # the 0.1 uV floor

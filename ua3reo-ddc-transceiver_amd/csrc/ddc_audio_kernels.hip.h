@@ -913,6 +913,12 @@ __global__ void ddc_audio_update_k(AudioState *__restrict__ states, uint32_t lo,
     s.agc_down = s.agc_up / 10.0f;
 }
 
+// clears the S-meter extremes of one channel once they have been read
+__global__ void ddc_audio_smeter_clear_k(AudioState *__restrict__ states, uint32_t ch)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { states[ch].smeter_max = 0; states[ch].smeter_min = 0; }
+}
+
 /* ---- single stages, for callers that drive the firmware's fine-grained functions ---- */
 
 /* One stage of the RX audio path on one channel's state, one thread:

@@ -962,6 +962,47 @@ int ddc_fft_move_waterfall(ddc_ctx *ctx, int32_t channel, int32_t freq_diff_hz)
     return 0;
 }
 
+// log10f_fast of the firmware (functions.c:247-260): a cubic in the mantissa
+static float log10f_fast(float X)
+{
+    float Y, F;
+    int E;
+    F = frexpf(fabsf(X), &E);
+    Y = 1.23149591368684f;
+    Y *= F;
+    Y += -4.11852516267426f;
+    Y *= F;
+    Y += 6.02197014179219f;
+    Y *= F;
+    Y += -3.13396450166353f;
+    Y += E;
+    return (Y * 0.3010299956639812f);
+}
+
+int ddc_audio_smeter_dbm(ddc_ctx *ctx, int32_t channel, float *dbm)
+{
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    if (channel < 0 || !dbm) return fail(ctx, -EINVAL, "ddc_audio_smeter_dbm needs one channel and an output");
+    if (!ctx->audio_ready[channel]) return fail(ctx, -EINVAL, "ddc_audio_configure has not been called for this channel");
+    ddc_audio_status st;
+    rc = ddc_audio_get_status(ctx, channel, &st);
+    if (rc) return rc;
+    const float rf_gain = ctx->audio_cfg[channel].rf_gain;
+    // stm32f4xx_it.c:401-409: 16-bit bus samples -> 12-bit ADC scale -> volts (ADC_VREF 1.0) -> RMS ->
+    // antenna side of the 1:4 transformer with the S9 calibration factor 0.2 -> dBm into 50 ohm
+    float vpp = (st.smeter_max / rf_gain) - (st.smeter_min / rf_gain);
+    for (int i = 0; i < (16 - 12); i++) vpp = vpp / 2;
+    const float adc_vpp = vpp * 1.0f / ((float)pow(2.0, 12) - 1);
+    const float vrms = adc_vpp * 0.3535f;
+    float rf_in = (vrms / 4) * 0.2f;
+    if (rf_in < 0.0000001f) rf_in = 0.0000001f;
+    *dbm = 10 * log10f_fast((rf_in * rf_in) / (50.0f * 0.001f));
+    hipLaunchKernelGGL(ddc::ddc_audio_smeter_clear_k, dim3(1), dim3(64), 0, ctx->stream, ctx->d_audio, (uint32_t)channel);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int ddc_audio_stage(ddc_ctx *ctx, int32_t channel, int stage, int arg, float *buf, int n)
 {
     int rc = check_channel(ctx, channel);

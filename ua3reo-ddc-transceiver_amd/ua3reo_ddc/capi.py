@@ -106,6 +106,7 @@ def lib():
     L.ddc_state_restore.argtypes = [vp, vp, sz]
     L.ddc_audio_configure.argtypes = [vp, i32, vp]
     L.ddc_audio_update.argtypes = [vp, i32, vp]
+    L.ddc_audio_smeter_dbm.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.ddc_fft_get_waterfall.argtypes = [vp, i32, vp]
     L.ddc_fft_move_waterfall.argtypes = [vp, i32, i32]
     L.ddc_audio_stage.argtypes = [vp, i32, C.c_int, C.c_int, vp, C.c_int]
@@ -303,6 +304,11 @@ class Ddc:
         rows = np.zeros((self.n_channels, nf, 256), np.uint16)
         self._check(self._L.ddc_fft_process(self._h, _np_ptr(s), s.shape[1], _np_ptr(bins), _np_ptr(rows)))
         return bins, rows
+
+    def smeter_dbm(self, channel):
+        v = C.c_float()
+        self._check(self._L.ddc_audio_smeter_dbm(self._h, channel, C.byref(v)))
+        return v.value
 
     def fft_waterfall(self, channel):
         out = np.zeros((50, 256), np.uint16)
