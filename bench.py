@@ -127,14 +127,22 @@ def main():
                          "--samples 4194304)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU; "
+                         "needs a torch.distributed launch)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # stdout carries the one JSON line: RCCL's own banner / debug text goes to stderr
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -155,7 +163,8 @@ def main():
     # step k overlaps the compute of step k+1
     outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
     out = outs[0]
-    gathered = torch.zeros((world * 2, nch, nf, 2), dtype=torch.int16, device=dev) if world > 1 else None
+    do_gather = world > 1 or args.force_gather
+    gathered = torch.zeros((world * 2, nch, nf, 2), dtype=torch.int16, device=dev) if do_gather else None
     with_fft = args.workload == "ddc+fft"
     if with_fft:
         assert nf % 512 == 0, "ddc+fft needs samples to be a multiple of 512*1024"
@@ -167,7 +176,7 @@ def main():
     if with_fft:
         ctx.audio_configure(ua3reo_ddc.audio_params(mode="USB", fft_averaging=4))
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if do_gather else None
     computed = [torch.cuda.Event(), torch.cuda.Event()]
     gathered_ev = [torch.cuda.Event(), torch.cuda.Event()]
     step_no = [0]
@@ -177,12 +186,12 @@ def main():
         b = step_no[0] & 1
         step_no[0] += 1
         o = outs[b]
-        if world > 1 and step_no[0] > 2:
+        if do_gather and step_no[0] > 2:
             ext.wait_event(gathered_ev[b])  # the gather that last read this buffer
         ctx.rx_process_dev(adc.data_ptr(), rb, S, o[0].data_ptr(), o[1].data_ptr())
         if with_fft:
             ctx.fft_process_dev(o[0].data_ptr(), nf, fft_bins.data_ptr(), fft_rows.data_ptr())
-        if world > 1:
+        if do_gather:
             computed[b].record(ext)
             comm.wait_event(computed[b])
             with torch.cuda.stream(comm):
