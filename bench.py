@@ -34,6 +34,20 @@ BYTES_PER_CHANNEL_SAMPLE = 1.5 + 8.0 / 1024.0  # packed ADC read + SPEC/VOICE in
 FS_ADC = 49152000
 
 
+class _StdoutToStderr:
+    """Points file descriptor 1 at stderr for a while: stdout is reserved for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def synth_rows(n_channels, samples, chan0, device, seed):
     """Packed 12-bit rows [n_channels][samples*3/2] on the device: per channel two
     tones (1400 and 300 LSB) at f_c = 1 MHz + 48 kHz*channel and +1 kHz, plus
@@ -144,7 +158,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():  # the communicator prints its version banner when it is built
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
     else:
         dist = None
         torch.cuda.set_device(local_rank)
