@@ -161,7 +161,7 @@ __device__ __forceinline__ void unpack8(uint32_t d0, uint32_t d1, uint32_t d2, i
 
 // Running sums over the chunk steps of one window.  T[i][q] ends as
 // sum_a C(a'+q, q) mu_i(a); the widths are the smallest that provably hold the
-// value for 15-bit inputs (bounds in tools/cic_math.py / DESIGN.md).
+// value for 15-bit inputs (the bounds are derived in tools/cic_math.py).
 struct Cascade {
     int t00, t01, t02, t03, t10, t11, t20, t30;
     long long t04, t12, t13, t21, t22, t31, t40;
