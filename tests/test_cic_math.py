@@ -35,11 +35,25 @@ def test_coef_and_gamma_tables():
 
 
 def test_local_weights_fit_the_packed_dot_product():
-    # 16-bit weights, and 32-bit sums for 15-bit data
+    # 16-bit weights, and 32-bit sums for doubled 15-bit data
     for i in range(5):
         w = [cm.psi(i, s) for s in range(32)]
         assert max(abs(v) for v in w) < 32768
-        assert sum(abs(v) for v in w) * (1 << 14) < (1 << 31)
+        assert sum(abs(v) for v in w) * (1 << 15) < (1 << 31)
+
+
+def test_cascade_widths_match_the_kernel():
+    """The kernel carries 2 x in 16-bit fields; the running sums it keeps in 32 bits
+    (Cascade in csrc/ddc_rx_kernels.hip.h) are exactly those the bound allows."""
+    w = cm.cascade_widths(2 * 16384)
+    assert all(b <= 32 for b in w["mu"])
+    narrow = {k for k, b in w["T"].items() if b <= 32}
+    assert narrow == {(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (2, 0)}
+    assert all(b <= 64 for b in w["T"].values())
+    src = open(os.path.join(os.path.dirname(cm.__file__), "..", "ua3reo-ddc-transceiver_amd", "csrc",
+                            "ddc_rx_kernels.hip.h")).read()
+    assert "int t00, t01, t02, t10, t11, t20;" in src
+    assert "long long t03, t04, t12, t13, t21, t22, t30, t31, t40;" in src
 
 
 def test_sf_constants(orc):

@@ -127,6 +127,27 @@ def sf_constants(sf_table):
     raise AssertionError("no (K, r) reproduces the fine sine ROM")
 
 
+def cascade_widths(xmax=2 * 16384):
+    """Bits each running sum T[i][q] of the GPU cascade (and each chunk moment mu_i)
+    needs, for mixer fields of magnitude <= xmax (the kernel carries 2 x, |x| <= 2^14).
+
+    After the sixteen natural chunk steps of a window and the hand-over of the five
+    samples before it (weight C(16+q, q)),
+        |T[i][q]| <= xmax * (sum_s |PSI[i][s]| * C(16+q, q+1) + sum_{s>=27} |PSI[i][s]| * C(16+q, q)),
+    and every intermediate value is bounded by the same sum.  Returns
+    {"mu": [bits...], "T": {(i, q): bits}} with bits counting the sign.
+    """
+    out = {"mu": [], "T": {}}
+    for i in range(NST):
+        sw = sum(abs(psi(i, s)) for s in range(CH))
+        tail = sum(abs(psi(i, s)) for s in range(CH - SHIFT, CH))
+        out["mu"].append((xmax * sw).bit_length() + 1)
+        for q in range(NST - i):
+            b = xmax * (sw * comb(16 + q, q + 1) + tail * comb(16 + q, q))
+            out["T"][(i, q)] = b.bit_length() + 1
+    return out
+
+
 # ---- slow model of the kernel data flow --------------------------------------
 
 def block_moments(x_prev5, x_blk):

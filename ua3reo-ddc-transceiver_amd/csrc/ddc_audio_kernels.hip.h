@@ -459,90 +459,110 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
 
 /* ---- FFT panadapter ---------------------------------------------------------- */
 
-/* Pass A (thread = channel): DC filter and optional notch over the call's frames
- * of 512 SPEC samples, in sequence.  Without zoom the float I/Q go to
- * work[channel][n]; with zoom M the stream is low-passed (4 biquads), decimated
- * by M (4-tap FIR) and appended behind the 512 - 512/M samples kept from earlier
- * frames: work[channel][512 - 512/M + n/M], where FFT frame f is the 512 samples
- * starting at f * 512/M (the firmware's sliding FFTInput_ZOOMFFT buffer). */
+/* Pass A (lane = one branch, I or Q, of one channel): DC filter and optional notch
+ * over the call's frames of 512 SPEC samples, in sequence; the two branches never
+ * meet before the FFT, so they run in neighbouring lanes.  The work buffer is
+ * planar: work[channel][branch][work_pitch] floats.  Without zoom the samples
+ * go to [n]; with zoom M the stream is low-passed (4 biquads), decimated by M
+ * (4-tap FIR) and appended behind the 512 - 512/M samples kept from earlier
+ * frames: [512 - 512/M + n/M], where FFT frame f is the 512 samples starting at
+ * f * 512/M (the firmware's sliding FFTInput_ZOOMFFT buffer). */
+template <uint32_t M>
 __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__ states, ZoomState *__restrict__ zooms,
                                                         uint32_t n_ch, const int16_t *__restrict__ spec_iq, uint32_t n,
-                                                        float2 *__restrict__ work, uint32_t work_pitch)
+                                                        float *__restrict__ work, uint32_t work_pitch)
 {
-    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ch = id >> 1, q = id & 1u; // q = 0: I branch, 1: Q branch
     if (ch >= n_ch) return;
     AudioState &s = states[ch];
     ZoomState &z = zooms[ch];
-    float dx4 = s.dc_x[4], dy4 = s.dc_y[4], dx5 = s.dc_x[5], dy5 = s.dc_y[5];
-    float ni[2] = { s.notch_fi[0], s.notch_fi[1] }, nq[2] = { s.notch_fq[0], s.notch_fq[1] };
+    float dx = s.dc_x[4 + q], dy = s.dc_y[4 + q];
+    float *nsave = q ? s.notch_fq : s.notch_fi;
+    float nd[2] = { nsave[0], nsave[1] };
     float c[5];
     for (int i = 0; i < 5; i++) c[i] = s.notch_c[i];
-    const bool notch = s.p.notch, swap = s.p.iq_swap;
-    const uint32_t M = z.zoom > 1 ? z.zoom : 1;
+    const bool notch = s.p.notch;
+    // the half of a packed SPEC word this lane filters (I is the low half)
+    const uint32_t half_off = ((q ^ (s.p.iq_swap ? 1u : 0u)) & 1u) * 16u;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(spec_iq) + (size_t)ch * n;
-    float2 *dst = work + (size_t)ch * work_pitch;
+    float *dst = work + ((size_t)ch * 2 + q) * work_pitch;
     const float A1 = 0.99951171875f;
-    float zc[20], zf[4], bi[16], bq[16], wi[4], wq[4]; // wi/wq: the newest four low-passed samples
-    uint32_t keep = 0;
+    float zc[20], zf[4], bs[16], w[4]; // w: the newest four low-passed samples
+    constexpr uint32_t keep = M > 1 ? 512 - 512 / M : 0;
     if (M > 1) {
+        float *bq = q ? z.bq_q : z.bq_i, *dec = q ? z.dec_q : z.dec_i;
         for (int i = 0; i < 20; i++) zc[i] = z.c[i];
         for (int i = 0; i < 4; i++) zf[i] = z.fir[i];
-        for (int i = 0; i < 16; i++) { bi[i] = z.bq_i[i]; bq[i] = z.bq_q[i]; }
-        for (int i = 0; i < 3; i++) { wi[i + 1] = z.dec_i[i]; wq[i + 1] = z.dec_q[i]; }
-        keep = 512 - 512 / M;
-        for (uint32_t i = 0; i < keep; i++) dst[i] = z.hist[i];
+        for (int i = 0; i < 16; i++) bs[i] = bq[i];
+        for (int i = 0; i < 3; i++) w[i + 1] = dec[i];
+        for (uint32_t i = 0; i < keep; i++) dst[i] = q ? z.hist[i].y : z.hist[i].x;
     }
-    // 16 samples per trip: four 16-byte loads in flight instead of one dword per
-    // dependent step (n is a multiple of 512, rows are 16-byte aligned)
-    for (uint32_t i0 = 0; i0 < n; i0 += 16) {
-        uint4 in4[4];
+    // 16 samples (64 bytes) per trip.  A lane pair walks one channel, so a trip's
+    // loads touch memory nobody else has warmed; four trips are kept in flight in a
+    // register ring so that their latency hides behind the recursion of the three
+    // trips before (n is a multiple of 512, rows are 16-byte aligned).
+    constexpr int kRing = 4;
+    uint4 ring[kRing][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) in4[k] = reinterpret_cast<const uint4 *>(src + i0)[k];
+    for (int r = 0; r < kRing; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) ring[r][k] = reinterpret_cast<const uint4 *>(src + 16 * r)[k];
+    auto trip = [&](const uint4 (&in4)[4], const uint32_t i0) {
         const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
                                   in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
-        float2 out[16];
+        float out[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-        const uint32_t i = i0 + k;
-        const uint32_t v = in[k];
-        float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
-        if (swap) { const float t = fi; fi = fq; fq = t; }
-        { const float d = fi - dx4; const float a = A1 * dy4; const float o = d + a; dx4 = fi; dy4 = o; fi = o; }
-        { const float d = fq - dx5; const float a = A1 * dy5; const float o = d + a; dx5 = fq; dy5 = o; fq = o; }
-        if (notch) { fi = biquad_step(c, ni, fi); fq = biquad_step(c, nq, fq); }
-        if (M == 1) { out[k] = make_float2(fi, fq); continue; }
+            float f = (float)(int)__builtin_amdgcn_sbfe(in[k], half_off, 16u); // the builtin is typed unsigned
+            { const float d = f - dx; const float a = A1 * dy; const float o = d + a; dx = f; dy = o; f = o; }
+            if (notch) f = biquad_step(c, nd, f);
+            if (M == 1) { out[k] = f; continue; }
 #pragma unroll
-        for (int sg = 0; sg < 4; sg++) { // arm_biquad_cascade_df1_f32: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2
-            const float b0 = zc[5 * sg], b1 = zc[5 * sg + 1], b2 = zc[5 * sg + 2], a1 = zc[5 * sg + 3], a2 = zc[5 * sg + 4];
-            const float yi = (b0 * fi) + (b1 * bi[4 * sg]) + (b2 * bi[4 * sg + 1]) + (a1 * bi[4 * sg + 2]) + (a2 * bi[4 * sg + 3]);
-            bi[4 * sg + 1] = bi[4 * sg]; bi[4 * sg] = fi; bi[4 * sg + 3] = bi[4 * sg + 2]; bi[4 * sg + 2] = yi;
-            fi = yi;
-            const float yq = (b0 * fq) + (b1 * bq[4 * sg]) + (b2 * bq[4 * sg + 1]) + (a1 * bq[4 * sg + 2]) + (a2 * bq[4 * sg + 3]);
-            bq[4 * sg + 1] = bq[4 * sg]; bq[4 * sg] = fq; bq[4 * sg + 3] = bq[4 * sg + 2]; bq[4 * sg + 2] = yq;
-            fq = yq;
-        }
-        wi[0] = wi[1]; wi[1] = wi[2]; wi[2] = wi[3]; wi[3] = fi;
-        wq[0] = wq[1]; wq[1] = wq[2]; wq[2] = wq[3]; wq[3] = fq;
-        if (i % M == 0) { // arm_fir_decimate_f32: the window of output m ends at sample m * M
-            float ai = 0.0f, aq = 0.0f;
+            for (int sg = 0; sg < 4; sg++) { // arm_biquad_cascade_df1_f32: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2
+                const float b0 = zc[5 * sg], b1 = zc[5 * sg + 1], b2 = zc[5 * sg + 2], a1 = zc[5 * sg + 3], a2 = zc[5 * sg + 4];
+                const float y = (b0 * f) + (b1 * bs[4 * sg]) + (b2 * bs[4 * sg + 1]) + (a1 * bs[4 * sg + 2]) + (a2 * bs[4 * sg + 3]);
+                bs[4 * sg + 1] = bs[4 * sg]; bs[4 * sg] = f; bs[4 * sg + 3] = bs[4 * sg + 2]; bs[4 * sg + 2] = y;
+                f = y;
+            }
+            w[0] = w[1]; w[1] = w[2]; w[2] = w[3]; w[3] = f;
+            if (k % M == 0) { // arm_fir_decimate_f32: the window of output m ends at sample m * M (i0 is a multiple of 16)
+                float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { ai += wi[k] * zf[k]; aq += wq[k] * zf[k]; }
-            dst[keep + i / M] = make_float2(ai, aq);
-        }
+                for (int kk = 0; kk < 4; kk++) acc += w[kk] * zf[kk];
+                dst[keep + (i0 + k) / M] = acc;
+            }
         }
         if (M == 1) {
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                reinterpret_cast<float4 *>(dst + i0)[k] = make_float4(out[2 * k].x, out[2 * k].y, out[2 * k + 1].x, out[2 * k + 1].y);
+            for (int k = 0; k < 4; k++)
+                reinterpret_cast<float4 *>(dst + i0)[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+        }
+    };
+    for (uint32_t i0 = 0; i0 < n; i0 += 16 * kRing) {
+#pragma unroll
+        for (int r = 0; r < kRing; r++) {
+            uint4 cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = ring[r][k];
+            const uint32_t ahead = i0 + 16 * (r + kRing);
+            if (ahead < n) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) ring[r][k] = reinterpret_cast<const uint4 *>(src + ahead)[k];
+            }
+            trip(cur, i0 + 16 * r);
         }
     }
-    s.dc_x[4] = dx4; s.dc_y[4] = dy4; s.dc_x[5] = dx5; s.dc_y[5] = dy5;
-    s.notch_fi[0] = ni[0]; s.notch_fi[1] = ni[1]; s.notch_fq[0] = nq[0]; s.notch_fq[1] = nq[1];
+    s.dc_x[4 + q] = dx; s.dc_y[4 + q] = dy;
+    if (notch) { nsave[0] = nd[0]; nsave[1] = nd[1]; }
     if (M > 1) {
-        for (int i = 0; i < 16; i++) { z.bq_i[i] = bi[i]; z.bq_q[i] = bq[i]; }
-        for (int i = 0; i < 3; i++) { z.dec_i[i] = wi[i + 1]; z.dec_q[i] = wq[i + 1]; }
+        float *bq = q ? z.bq_q : z.bq_i, *dec = q ? z.dec_q : z.dec_i;
+        for (int i = 0; i < 16; i++) bq[i] = bs[i];
+        for (int i = 0; i < 3; i++) dec[i] = w[i + 1];
         const uint32_t produced = n / M;
-        for (uint32_t i = 0; i < keep; i++) z.hist[i] = dst[produced + i];
+        for (uint32_t i = 0; i < keep; i++) {
+            if (q) z.hist[i].y = dst[produced + i]; else z.hist[i].x = dst[produced + i];
+        }
     }
 }
 
@@ -552,21 +572,20 @@ __constant__ float2 c_fft_twiddle[256]; // exp(-2 pi i k / 512)
 /* Pass B (workgroup of 64 = one frame of one channel): Hamming window, 512-point
  * radix-2 FFT in LDS, magnitude, 2:1 bin average, bin 0 := bin 1.
  * mags: [channel][frames][256]. */
-__global__ __launch_bounds__(64) void ddc_fft_frames(const float2 *__restrict__ work, uint32_t frames_per_ch,
+__global__ __launch_bounds__(64) void ddc_fft_frames(const float *__restrict__ work, uint32_t frames_per_ch,
                                                      uint32_t work_pitch, uint32_t frame_step,
                                                      float *__restrict__ mags)
 {
     __shared__ float re[512], im[512];
     const uint32_t fr = blockIdx.x, t = threadIdx.x;
     const uint32_t ch = fr / frames_per_ch, f = fr - ch * frames_per_ch;
-    const float2 *x = work + (size_t)ch * work_pitch + (size_t)f * frame_step;
+    const float *xr = work + (size_t)ch * 2 * work_pitch + (size_t)f * frame_step, *xi = xr + work_pitch;
     for (int j = 0; j < 8; j++) {
         const int i = t + 64 * j;
         const int r = (int)(__brev((unsigned)i) >> 23); // 9-bit reversal
-        const float2 v = x[i];
         const float w = c_fft_window[i];
-        re[r] = w * v.x;
-        im[r] = w * v.y;
+        re[r] = w * xr[i];
+        im[r] = w * xi[i];
     }
     __syncthreads();
     for (int len = 2, lg = 1; len <= 512; len <<= 1, lg++) {

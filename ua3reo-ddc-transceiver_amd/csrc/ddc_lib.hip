@@ -57,12 +57,12 @@ struct ddc_ctx {
     std::vector<uint8_t> audio_ready;  // per channel: ddc_audio_configure seen
     std::vector<uint8_t> zoom_of;      // per channel: configured FFT zoom
     std::vector<ddc_audio_params> audio_cfg; // per channel: what ddc_audio_configure was given
-    float2 *d_fft_work = nullptr;      // [ch][n][2] prefiltered SPEC
+    float2 *d_fft_work = nullptr;      // [ch][I, Q][pitch] floats: prefiltered SPEC, planar
     float *d_fft_mag = nullptr;        // [ch][frames][256]
     uint16_t *d_fft_rows = nullptr;    // [ch][frames][256] colour rows when the caller wants none
     uint16_t *d_wtf = nullptr;         // [ch][50][256] waterfall, row 0 newest
     size_t fft_cap = 0;                // frames per channel d_fft_mag holds
-    size_t fft_work_cap = 0;           // float2 per channel d_fft_work holds
+    size_t fft_work_cap = 0;           // floats per channel and branch d_fft_work holds
     void *d_stage[3] = {nullptr, nullptr, nullptr}; // host-pointer entry points
     size_t stage_cap[3] = {0, 0, 0};
     // optional per-call timing: HIP events on the ctx stream around the front
@@ -845,7 +845,7 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
     // one launch handles one zoom factor: the frame step in the work buffer depends on it
     if (ctx->fft_zoom_all == 0) return fail(ctx, -EINVAL, "ddc_fft_process needs the same fft_zoom on every channel");
     const uint32_t M = ctx->fft_zoom_all, zw = 512 / M;
-    const size_t pitch = (512 - zw) + fpc * zw; // float2 per channel
+    const size_t pitch = (512 - zw) + fpc * zw; // floats per channel and branch
     if (fpc > ctx->fft_cap || pitch > ctx->fft_work_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_fft_work) (void)hipFree(ctx->d_fft_work);
@@ -858,9 +858,23 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
         ctx->fft_cap = fpc;
         ctx->fft_work_cap = pitch;
     }
-    hipLaunchKernelGGL(ddc::ddc_fft_prefilter, dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, ctx->stream, ctx->d_audio,
-                       ctx->d_zoom, (uint32_t)nch, spec_iq, (uint32_t)n_frames, ctx->d_fft_work, (uint32_t)pitch);
-    hipLaunchKernelGGL(ddc::ddc_fft_frames, dim3((unsigned)(nch * fpc)), dim3(64), 0, ctx->stream, ctx->d_fft_work,
+    {
+        const dim3 grid((unsigned)((2 * nch + 63) / 64)), block(64);
+        float *work = reinterpret_cast<float *>(ctx->d_fft_work);
+#define DDC_PREFILTER(Z) hipLaunchKernelGGL(ddc::ddc_fft_prefilter<Z>, grid, block, 0, ctx->stream, ctx->d_audio, \
+                                            ctx->d_zoom, (uint32_t)nch, spec_iq, (uint32_t)n_frames, work, (uint32_t)pitch)
+        switch (M) {
+        case 1: DDC_PREFILTER(1); break;
+        case 2: DDC_PREFILTER(2); break;
+        case 4: DDC_PREFILTER(4); break;
+        case 8: DDC_PREFILTER(8); break;
+        case 16: DDC_PREFILTER(16); break;
+        default: return fail(ctx, -EINVAL, "fft_zoom must be 1, 2, 4, 8 or 16");
+        }
+#undef DDC_PREFILTER
+    }
+    hipLaunchKernelGGL(ddc::ddc_fft_frames, dim3((unsigned)(nch * fpc)), dim3(64), 0, ctx->stream,
+                       reinterpret_cast<const float *>(ctx->d_fft_work),
                        (uint32_t)fpc, (uint32_t)pitch, zw, ctx->d_fft_mag);
     hipLaunchKernelGGL(ddc::ddc_fft_level, dim3((unsigned)nch), dim3(256), 0, ctx->stream, ctx->d_audio, ctx->d_fft_mag,
                        (uint32_t)fpc, bins, rows ? rows : ctx->d_fft_rows, ctx->d_wtf);
@@ -1106,6 +1120,7 @@ namespace {
 struct StateSeg { void *dev; size_t bytes; };
 struct StateHeader { uint32_t magic, version, n_channels, n_seg; uint64_t total; };
 constexpr uint32_t kStateMagic = 0x43444455u; // "UDDC"
+constexpr uint32_t kStateVersion = 2;          // 2: window moments and mixer carries hold twice the CIC input
 
 std::vector<StateSeg> state_segments(ddc_ctx *ctx)
 {
@@ -1140,7 +1155,7 @@ int ddc_state_save(ddc_ctx *ctx, void *buf, size_t size)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     uint8_t *p = static_cast<uint8_t *>(buf);
     const auto segs = state_segments(ctx);
-    StateHeader h = { kStateMagic, 1, ctx->cfg.n_channels, (uint32_t)segs.size(), need };
+    StateHeader h = { kStateMagic, kStateVersion, ctx->cfg.n_channels, (uint32_t)segs.size(), need };
     memcpy(p, &h, sizeof h);
     p += sizeof h;
     for (const StateSeg &g : segs) {
@@ -1161,7 +1176,7 @@ int ddc_state_restore(ddc_ctx *ctx, const void *buf, size_t size)
     if (size < sizeof h) return fail(ctx, -EINVAL, "state blob truncated");
     memcpy(&h, buf, sizeof h);
     const auto segs = state_segments(ctx);
-    if (h.magic != kStateMagic || h.version != 1 || h.n_channels != ctx->cfg.n_channels || h.n_seg != segs.size() ||
+    if (h.magic != kStateMagic || h.version != kStateVersion || h.n_channels != ctx->cfg.n_channels || h.n_seg != segs.size() ||
         h.total != need || size < need)
         return fail(ctx, -EINVAL, "state blob does not match this ctx (magic / version / channel count / size)");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));

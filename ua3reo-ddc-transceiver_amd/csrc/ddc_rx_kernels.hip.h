@@ -17,7 +17,7 @@
  * channels parallelise over both.
  *
  * Kernel 1 (ddc_rx_front) is the only one that touches the ADC stream; it is
- * bound by vector-ALU issue (about 21 integer lane-ops per sample), reads every
+ * bound by vector-ALU issue (about 20 integer lane-ops per sample), reads every
  * ADC byte once (1.5 B per sample) and writes 80 B of moments per 512 samples.
  */
 #pragma once
@@ -112,24 +112,22 @@ __device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc27, uint
 }
 
 // NCO second half + mixer: 2*(sc*8191 + cc*sf + 4096) has the 12-bit mixer
-// operand (14-bit output >> 2) in bits 31..16.  Returns the two 15-bit CIC
-// inputs wrap23(adc * nco12) >> 8.
-__device__ __forceinline__ void nco_finish(const uint2 e, uint32_t w, int adc, int &xi, int &xq)
+// operand (14-bit output >> 2) in bits 31..16.  Returns the two 24-bit mixer
+// products adc * nco12; the CIC input is x = wrap23(product) >> 8.
+__device__ __forceinline__ void nco_finish(const uint2 e, uint32_t w, int adc, int &pi, int &pq)
 {
     const int s = dot2_sconst(e.x, w, 8192);
     const int c = dot2_sconst(e.y, w, 8192);
-    const int pi = __mul24(adc, s >> 16);
-    const int pq = __mul24(adc, c >> 16);
-    xi = sbfe_c<8, 15>(pi);
-    xq = sbfe_c<8, 15>(pq);
+    pi = __mul24(adc, s >> 16);
+    pq = __mul24(adc, c >> 16);
 }
 
-__device__ __forceinline__ void nco_mix(const uint2 *tab, uint32_t acc32, int adc, int &xi, int &xq)
+__device__ __forceinline__ void nco_mix(const uint2 *tab, uint32_t acc32, int adc, int &pi, int &pq)
 {
     uint2 e;
     uint32_t w;
     nco_fetch(tab, acc32, e, w);
-    nco_finish(e, w, adc, xi, xq);
+    nco_finish(e, w, adc, pi, pq);
 }
 
 // 16 bytes per lane from global memory straight into LDS (no VGPR round trip):
@@ -141,9 +139,18 @@ __device__ __forceinline__ void lds_dma16(const uint8_t *g, uint4 *lds_wave_base
         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ unsigned pack16(int lo, int hi)
+// Two mixer products -> the packed pair {2 x_lo, 2 x_hi} of 16-bit halves.
+// Bits 23..8 of a product are x except that the one product that overflows 23
+// bits (2^22 = -2048 * -2048) must wrap to -2^14; doubling the 16-bit field in
+// 16-bit arithmetic drops exactly that bit, and 2 x always fits.  Everything
+// downstream of the mixer therefore carries twice the CIC input; the last
+// kernel of the CIC takes its output bits one place higher.
+__device__ __forceinline__ unsigned pack_x2(int p_lo, int p_hi)
 {
-    return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u);
+    const unsigned y = __builtin_amdgcn_perm((unsigned)p_hi, (unsigned)p_lo, 0x06050201u);
+    unsigned r;
+    asm("v_pk_add_u16 %0, %1, %1" : "=v"(r) : "v"(y));
+    return r;
 }
 
 // eight 12-bit samples from three dwords
@@ -161,14 +168,14 @@ __device__ __forceinline__ void unpack8(uint32_t d0, uint32_t d1, uint32_t d2, i
 
 // Running sums over the chunk steps of one window.  T[i][q] ends as
 // sum_a C(a'+q, q) mu_i(a); the widths are the smallest that provably hold the
-// value for 15-bit inputs (the bounds are derived in tools/cic_math.py).
+// value for doubled 15-bit inputs (cascade_widths() in tools/cic_math.py).
 struct Cascade {
-    int t00, t01, t02, t03, t10, t11, t20, t30;
-    long long t04, t12, t13, t21, t22, t31, t40;
+    int t00, t01, t02, t10, t11, t20;
+    long long t03, t04, t12, t13, t21, t22, t30, t31, t40;
     __device__ __forceinline__ void clear()
     {
-        t00 = t01 = t02 = t03 = t10 = t11 = t20 = t30 = 0;
-        t04 = t12 = t13 = t21 = t22 = t31 = t40 = 0;
+        t00 = t01 = t02 = t10 = t11 = t20 = 0;
+        t03 = t04 = t12 = t13 = t21 = t22 = t30 = t31 = t40 = 0;
     }
     __device__ __forceinline__ void step(const int (&mu)[5])
     {
@@ -182,7 +189,7 @@ struct Cascade {
     // cascade has run, would have left behind: C(16 + q, q) * mu[i] in T[i][q].
     __device__ __forceinline__ void inject_first(const int (&mu)[5])
     {
-        t00 += mu[0]; t01 += 17 * mu[0]; t02 += 153 * mu[0]; t03 += 969 * mu[0]; t04 += 4845ll * mu[0];
+        t00 += mu[0]; t01 += 17 * mu[0]; t02 += 153 * mu[0]; t03 += 969ll * mu[0]; t04 += 4845ll * mu[0];
         t10 += mu[1]; t11 += 17 * mu[1]; t12 += 153ll * mu[1]; t13 += 969ll * mu[1];
         t20 += mu[2]; t21 += 17ll * mu[2]; t22 += 153ll * mu[2];
         t30 += mu[3]; t31 += 17ll * mu[3];
@@ -282,11 +289,11 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
     unsigned pi[4], pq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int xi0, xq0, xi1, xq1;
-        nco_finish(e[2 * k], w[2 * k], a[2 * k], xi0, xq0);
-        nco_finish(e[2 * k + 1], w[2 * k + 1], a[2 * k + 1], xi1, xq1);
-        pi[k] = pack16(xi0, xi1);
-        pq[k] = pack16(xq0, xq1);
+        int pi0, pq0, pi1, pq1;
+        nco_finish(e[2 * k], w[2 * k], a[2 * k], pi0, pq0);
+        nco_finish(e[2 * k + 1], w[2 * k + 1], a[2 * k + 1], pi1, pq1);
+        pi[k] = pack_x2(pi0, pi1);
+        pq[k] = pack_x2(pq0, pq1);
     }
     pair_acc<4 * G + 0>(pi[0], pq[0], mi, mq);
     pair_acc<4 * G + 1>(pi[1], pq[1], mi, mq);
@@ -313,8 +320,8 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
  * p ^ swz(r); the swizzle makes the 16-byte reads of 16 consecutive threads hit
  * 16 different bank groups.
  *
- *   mom  [channel][kMomHist + n_blk][2][5] u64 : window moments, I then Q;
- *        this kernel writes records kMomHist + block
+ *   mom  [channel][kMomHist + n_blk][2][5] u64 : window moments (of 2 x), I then
+ *        Q; this kernel writes records kMomHist + block
  *   carry_in / carry_out [channel][6] : packed mixer outputs of the last six
  *        samples of the previous / this call (I pairs 13..15, Q pairs 13..15)
  */
@@ -456,13 +463,13 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
             uint32_t ph = (acc0[ch] + (b * (uint32_t)kBlk - 6u) * phi_in) >> 5;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                int xi0, xq0, xi1, xq1;
-                nco_mix(tab, ph, a[2 + 2 * k], xi0, xq0);
+                int pi0, pq0, pi1, pq1;
+                nco_mix(tab, ph, a[2 + 2 * k], pi0, pq0);
                 ph += phi32;
-                nco_mix(tab, ph, a[3 + 2 * k], xi1, xq1);
+                nco_mix(tab, ph, a[3 + 2 * k], pi1, pq1);
                 ph += phi32;
-                pki[k] = pack16(xi0, xi1);
-                pkq[k] = pack16(xq0, xq1);
+                pki[k] = pack_x2(pi0, pi1);
+                pkq[k] = pack_x2(pq0, pq1);
             }
         } else {
 #pragma unroll
@@ -535,7 +542,8 @@ __device__ __forceinline__ unsigned long long coef_mul(int j, int e, unsigned lo
 /*
  * Kernel 2.  rx_cic output m of this call from the moments of windows m-5..m-1
  * (records m..m+4): y = wrap60(sum_j sum_e COEF[j][e] * B[m-1-j][e]) >> 44
- * (FPGA/rx_cic.vhd:391).  cic: [channel][kCicHist + n_blk][2] int16.
+ * (FPGA/rx_cic.vhd:391); the records hold 2 B, so the bits sit one place up.
+ * cic: [channel][kCicHist + n_blk][2] int16.
  */
 __global__ __launch_bounds__(256) void ddc_rx_cic_combine(const unsigned long long *__restrict__ mom, uint32_t n_blk,
                                                          uint32_t tiles, int16_t *__restrict__ cic)
@@ -563,8 +571,8 @@ __global__ __launch_bounds__(256) void ddc_rx_cic_combine(const unsigned long lo
         }
     }
     int16_t *o = cic + ((size_t)ch * (kCicHist + n_blk) + kCicHist + m) * 2;
-    o[0] = (int16_t)((long long)(acc[0] << 4) >> 48);
-    o[1] = (int16_t)((long long)(acc[1] << 4) >> 48);
+    o[0] = (int16_t)((long long)(acc[0] << 3) >> 48);
+    o[1] = (int16_t)((long long)(acc[1] << 3) >> 48);
 }
 
 /*
