@@ -56,6 +56,20 @@ def test_cascade_widths_match_the_kernel():
     assert "long long t03, t04, t12, t13, t21, t22, t30, t31, t40;" in src
 
 
+def test_tx_walk_values_are_exact_in_double():
+    """ddc_tx_duc walks the interpolator polynomial in double precision: every
+    value must be an integer below 2^52 (p carries an extra 1/2 - 2^37)."""
+    from math import comb
+    C = cm.coef_table()
+    for u in (0, 1, 7, 255, 503, 504, 511):
+        taps = [sum(C[q][e] * comb(u + e, e) for e in range(5)) for q in range(5)]
+        assert min(taps) >= 0 and sum(taps) == 1 << 36     # |P| <= 2^36 * 2^15
+    assert (1 << 51) + (1 << 37) + 1 < (1 << 52)
+    cb = [32768 * sum(abs(C[q][e]) for q in range(5)) for e in range(5)]
+    for k in range(1, 5):                                   # backward differences of order k
+        assert max(sum(cb[e] * comb(u + e - k, e - k) for e in range(k, 5)) for u in range(512)) < (1 << 52)
+
+
 def test_sf_constants(orc):
     sf = orc.nco_tables()[2]
     K, r = cm.sf_constants([int(v) for v in sf])

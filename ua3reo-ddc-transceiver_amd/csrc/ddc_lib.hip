@@ -7,6 +7,7 @@
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <string>
@@ -14,6 +15,7 @@
 
 #include "../../include/ua3reo_ddc.h"
 #include "ddc_rx_kernels.hip.h"
+#include "ddc_rx_front_mm.hip.h"
 #include "ddc_tx_kernels.hip.h"
 #include "ddc_audio_kernels.hip.h"
 
@@ -27,6 +29,8 @@ struct ddc_ctx {
     uint32_t *d_carry[2] = {nullptr, nullptr};
     int carry_sel = 0;
     uint2 *d_nco_tab = nullptr;
+    uint4 *d_mm_tab = nullptr;         // byte planes of the window weights (B operand of ddc_rx_front_mm)
+    bool front_dot2 = false;           // UA3REO_DDC_FRONT=dot2: the vector-ALU-only ingest kernel instead
     // work buffers, sized for cap_blk blocks of 512 samples per channel
     uint32_t cap_blk = 0;
     uint32_t last_blk = 0;
@@ -247,6 +251,17 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         return bail(-EFAULT);
     }
     CREATE_TRY(hipMemcpyAsync(ctx->d_nco_tab, tab.data(), 2048 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    {
+        std::vector<uint8_t> mm(ddc::kMmTabRows * 256);
+        if (!ddc::build_mm_table(mm.data())) {
+            ctx->err = "a window weight does not fit its byte planes";
+            return bail(-EFAULT);
+        }
+        CREATE_TRY(hipMalloc(&ctx->d_mm_tab, mm.size()));
+        CREATE_TRY(hipMemcpy(ctx->d_mm_tab, mm.data(), mm.size(), hipMemcpyHostToDevice));
+        const char *sel = getenv("UA3REO_DDC_FRONT");
+        ctx->front_dot2 = sel && !strcmp(sel, "dot2");
+    }
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
@@ -315,7 +330,7 @@ void ddc_destroy(ddc_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
+    void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mm_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
                      ctx->d_out, ctx->d_tx_xs, ctx->d_fft_rows, ctx->d_wtf, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
                      ctx->d_stage[2] };
@@ -458,8 +473,15 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
     uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
-    ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
-        adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
+    // ddc_rx_front_mm addresses the 64 blocks of a wave with 32-bit offsets from the first one
+    const bool near_rows = (unsigned long long)(64u / n_blk + 2u) * row_bytes < (1ull << 32);
+    if (ctx->front_dot2 || !near_rows)
+        ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
+            adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
+    else
+        ddc::ddc_rx_front_mm<<<(total + ddc::kMmThreads - 1) / ddc::kMmThreads, ddc::kMmThreads, 0, st>>>(
+            adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab,
+            ctx->d_mm_tab);
     ctx->carry_sel ^= 1;
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
     const uint32_t ctiles = (n_blk + 255) / 256;

@@ -18,8 +18,8 @@
  * it with four running sums per sample (no recursion across segments).
  *
  * The kernel writes 2 bytes per DAC sample and reads 4 bytes per 1024 samples;
- * like the RX ingest it is bound by vector-ALU issue (NCO + two 64-bit
- * polynomial walks per sample).
+ * like the RX ingest it is bound by vector-ALU issue (NCO + two exact
+ * polynomial walks per sample, run in double precision).
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -73,27 +73,60 @@ __device__ __forceinline__ void nco14(const uint2 *tab, uint32_t acc32, int &s14
     c14 = dot2_sconst(e.y, w, 8192) >> 14;
 }
 
-// running-sum walk of sum_e c[e] * C(u+e, e), u = 0, 1, 2, ...
+// Running-sum walk of the interpolated tx_cic output over one segment,
+//   P(u) = sum_q p_q(u) y[G-1-q],  p_q(u) = sum_e COEF[q][e] C(u+e, e) = h[512 q + u]  (u = 0..511),
+// by its backward differences: one step is four additions.
+//
+// p_q(u) are the taps of (1,...,1)_512^{*5}: non-negative, and the five of one u
+// sum to 2^36.  So |P| <= 2^51 for 16-bit y, and P, its differences and every
+// partial sum of the start values below are integers a double holds exactly:
+// the walk runs as v_add_f64 (one issue slot each; a 64-bit integer add costs
+// two) and is started with 25 v_fma_f64 per branch.  p carries P + 1/2 - 2^37,
+// still exact, so that adding 1.5 * 2^90 rounds it (to nearest, never a tie) to
+// 2^38 * floor(P / 2^38) and leaves floor(P >> 38) in the low dword of the sum.
+__host__ __device__ constexpr long long tx_start_const(int u, int k, int q)
+{
+    // nabla^k p_q(u) = sum_{e>=k} COEF[q][e] C(u + e - k, e - k)
+    long long v = 0;
+    for (int e = k; e < 5; e++) v += COEF[q][e] * binom_gen(u + e - k, e - k);
+    return v;
+}
+constexpr bool tx_start_consts_exact()
+{
+    for (int u = 0; u <= 504; u += 504)
+        for (int k = 0; k < 5; k++) {
+            long long mag = 0;
+            for (int q = 0; q < 5; q++) {
+                const long long v = tx_start_const(u, k, q);
+                mag += v < 0 ? -v : v;
+            }
+            if (mag * 32768 >= (1ll << 52)) return false;
+        }
+    return true;
+}
+static_assert(tx_start_consts_exact(), "a start value of the TX walk would not be exact in double precision");
+
 struct PolyWalk {
-    long long q3, q2, q1, p, c4;
-    __device__ __forceinline__ void init(const long long (&c)[5])
+    double q3, q2, q1, p, c4;
+    static constexpr double kBias = 0.5 - 137438953472.0; // 1/2 - 2^37
+    static constexpr double kMagic = 0x1.8p+90;           // 1.5 * 2^90
+    // state at u = U (0 or 504) of the segment whose newest input word is y[0]
+    // (y[q] = q words older); B = 0 takes the I halves, 1 the Q halves
+    template <int U, int B>
+    __device__ __forceinline__ void start(const uint32_t (&y)[5])
     {
-        c4 = c[4];
-        q3 = c[3] + c[4];
-        q2 = c[2] + q3;
-        q1 = c[1] + q2;
-        p = c[0] + q1;
-    }
-    // the same walk entered at u = 504: p and its backward differences there,
-    // nabla^k p(504) = sum_{e>=k} c[e] C(504 + e - k, e - k)
-    __device__ __forceinline__ void init_at504(const long long (&c)[5])
-    {
-        const long long k1 = 505, k2 = 127765, k3 = 21592285, k4 = 2742220195ll; // C(504 + m, m)
-        c4 = c[4];
-        q3 = c[3] + c[4] * k1;
-        q2 = c[2] + c[3] * k1 + c[4] * k2;
-        q1 = c[1] + c[2] * k1 + c[3] * k2 + c[4] * k3;
-        p = c[0] + c[1] * k1 + c[2] * k2 + c[3] * k3 + c[4] * k4;
+        double v[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) v[q] = (double)(B ? (int)y[q] >> 16 : (int)(int16_t)(y[q] & 0xFFFFu));
+        double a[5] = { kBias, 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const double c = (double)tx_start_const(U, k, q);
+                if (c != 0.0) a[k] = __builtin_fma(c, v[q], a[k]);
+            }
+        p = a[0]; q1 = a[1]; q2 = a[2]; q3 = a[3]; c4 = a[4];
     }
     __device__ __forceinline__ void next()
     {
@@ -102,8 +135,8 @@ struct PolyWalk {
         q1 += q2;
         p += q1;
     }
-    // tx_cic output register: bits 59..46 of the 2^8-scaled sum
-    __device__ __forceinline__ int out14() const { return (int)(p >> 32) >> 6; }
+    // tx_cic output register: bits 59..46 of the 2^8-scaled sum = P >> 38
+    __device__ __forceinline__ int out14() const { return __double2loint(p + kMagic); }
 };
 
 /*
@@ -112,7 +145,7 @@ struct PolyWalk {
  * output is piecewise polynomial with pieces ("segments") that start 8 samples
  * into a block:
  *   segment G covers t = 512 G + 8 + u, u = 0..511,
- *   cic(t-3) = (sum_q p_q(u) y[G-1-q]) >> 38,  p_q(u) = sum_e COEF[q][e] C(u+e, e)
+ *   cic(t-3) = P_G(u) >> 38 with the input words y[G-1-q], q = 0..4
  *   dac[t]   = (((I*sin14 + Q*cos14)(phase(t-2)) >> 14) + 8191) & 0x3FFF
  * so the first 8 samples of block g come from segment g - 2 at u = 504..511 and
  * the other 504 from segment g - 1 at u = 0..503.
@@ -122,22 +155,6 @@ struct PolyWalk {
  * line-aligned), instead of 64 lanes writing 16 bytes each 1 KB apart.
  * ybuf: [channel][6 + n96][2]; dac: [channel][512 n96] uint16.
  */
-__device__ __forceinline__ void tx_segment_coeffs(const uint32_t *y, long long (&ci)[5], long long (&cq)[5])
-{
-#pragma unroll
-    for (int e = 0; e < 5; e++) { ci[e] = 0; cq[e] = 0; }
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-        const uint32_t v = y[-q];
-        const long long yi = (int16_t)(v & 0xFFFFu), yq = (int)v >> 16;
-#pragma unroll
-        for (int e = 0; e < 5; e++) {
-            ci[e] += COEF[q][e] * yi;
-            cq[e] += COEF[q][e] * yq;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ ybuf, uint32_t n96,
                                                   uint32_t total, const uint32_t *__restrict__ acc0,
                                                   const uint32_t *__restrict__ phi32v,
@@ -178,11 +195,13 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
     // buffer index of y[G-1] for segment G is G + 5 (six words of history in front)
     const uint32_t *ybase = reinterpret_cast<const uint32_t *>(ybuf) + (size_t)ch * (kTxYHist + n96);
     PolyWalk wi, wq;
+    uint32_t yw[6]; // yw[j] = y[g + 4 - j]: words 1..5 feed segment g - 2, words 0..4 segment g - 1
+#pragma unroll
+    for (int j = 0; j < 6; j++) yw[j] = ybase[4 + g - j];
     {
-        long long ci[5], cq[5];
-        tx_segment_coeffs(ybase + 3 + g, ci, cq); // segment g - 2
-        wi.init_at504(ci);
-        wq.init_at504(cq);
+        const uint32_t y5[5] = { yw[1], yw[2], yw[3], yw[4], yw[5] };
+        wi.start<504, 0>(y5);
+        wq.start<504, 1>(y5);
     }
     // stored phase / increment are << 10; the sample loop runs on the << 5 form of nco_fetch
     const uint32_t phi_in = phi32v[ch];
@@ -193,19 +212,19 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
 #pragma unroll 1
     for (int grp = 0; grp < 64; grp++) {
         if (grp == 1) { // the block's own segment starts here
-            long long ci[5], cq[5];
-            tx_segment_coeffs(ybase + 4 + g, ci, cq); // segment g - 1
-            wi.init(ci);
-            wq.init(cq);
+            const uint32_t y5[5] = { yw[0], yw[1], yw[2], yw[3], yw[4] };
+            wi.start<0, 0>(y5);
+            wq.start<0, 1>(y5);
         }
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             int s14, c14;
             nco14(tab, ph, s14, c14);
-            const int sum = __mul24(wi.out14(), s14) + __mul24(wq.out14(), c14) + (8191 << 14);
-            const uint32_t d = __builtin_amdgcn_ubfe((uint32_t)sum, 14, 14);
-            if (k & 1) w[k / 2] |= d << 16; else w[k / 2] = d;
+            const uint32_t sum = (uint32_t)(__mul24(wi.out14(), s14) + __mul24(wq.out14(), c14) + (8191 << 14));
+            // the DAC word is bits 27..14; two per dword
+            if (k & 1) w[k / 2] = ((sum << 2) & 0x3FFF0000u) | (w[k / 2] & ~0x3FFF0000u);
+            else w[k / 2] = __builtin_amdgcn_ubfe(sum, 14, 14);
             ph += phi32;
             wi.next();
             wq.next();
