@@ -302,3 +302,38 @@ def test_full_size_shard_properties(ddc, orc):
         ws, wv = orc.RxChain(phis[c]).run(x)
         assert np.array_equal(s1[c, : ns // 1024].cpu().numpy(), ws)
         assert np.array_equal(v1[c, : ns // 1024].cpu().numpy(), wv)
+
+
+@pytest.mark.parametrize("n_ch,samples,pitch_extra", [(3, 1024 * 40, 0), (200, 1024, 512), (70, 3072, 256)])
+def test_both_ingest_kernels_agree(ddc, orc, monkeypatch, n_ch, samples, pitch_extra):
+    """The library has two forms of the ingest kernel (window moments on the matrix
+    cores, the default, and on the vector ALU, UA3REO_DDC_FRONT=dot2, read when a
+    ctx is created).  Same inputs, two calls each: identical outputs, equal to the
+    oracle, including rail inputs (the one mixer product that wraps) and waves that
+    straddle many channels."""
+    rng = np.random.default_rng(1234 + n_ch)
+    adc = rng.integers(-2048, 2048, size=(n_ch, 2 * samples)).astype(np.int16)
+    adc[0, 100:700] = -2048
+    adc[-1, :] = np.where(rng.random(2 * samples) < 0.5, -2048, 2047)
+    phis = rng.integers(0, 1 << 22, n_ch).astype(np.uint32)
+    phis[0] = 3 << 20  # sin12 = -2048 at every sample
+    rb = samples // 2 * 3
+    res = {}
+    for form in ("mm", "dot2"):
+        if form == "dot2":
+            monkeypatch.setenv("UA3REO_DDC_FRONT", "dot2")
+        else:
+            monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
+        d = ddc.Ddc(n_ch)
+        d.tune_many(phis)
+        outs = []
+        for k in range(2):
+            rows = np.zeros((n_ch, rb + pitch_extra), np.uint8)
+            for c in range(n_ch):
+                rows[c, :rb] = ddc.pack_adc12(adc[c, k * samples:(k + 1) * samples])
+            outs.append(d.rx_process(rows, samples))
+        res[form] = (np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1))
+    assert np.array_equal(res["mm"][0], res["dot2"][0]) and np.array_equal(res["mm"][1], res["dot2"][1])
+    for c in (0, 1, n_ch // 2, n_ch - 1):
+        ws, wv = orc.RxChain(int(phis[c])).run(adc[c])
+        assert np.array_equal(res["mm"][0][c], ws) and np.array_equal(res["mm"][1][c], wv), c
