@@ -247,6 +247,20 @@ int ddc_audio_stage(ddc_ctx *ctx, int32_t channel, int stage, int arg, float *bu
  * peak-to-peak of the audio samples since the last reading -> dBm at the antenna
  * input (TRX_RX_dBm), with the firmware's log10f_fast; clears the extremes. */
 int ddc_audio_smeter_dbm(ddc_ctx *ctx, int32_t channel, float *dbm);
+/* The once-a-second front-end gain search of the firmware, TRX_DoAutoGain
+ * (trx_manager.c:268-356; AUTOGAIN_MAX_AMPLITUDE 1100 settings.h:25, ATT_DB 12 and
+ * PREAMP_GAIN_DB 20 settings.h:23-24, AUTOGAIN_CORRECTOR_WAITSTEP 7 trx_manager.h:9):
+ * from the ADC's largest amplitude since the last status read (TRX_ADC_MAXAMPLITUDE,
+ * byte 3-4 of ddc_get_status) it walks ATT -> none -> PREAMP+ATT -> PREAMP, waiting
+ * seven quiet calls before every step up and falling back when the ADC comes close
+ * to its rail.  Host-side state machine, one per channel, zero-initialised; the
+ * caller switches its relays (or scales its ADC rows) after `preamp` and `att`.
+ * Returns 1 when the call changed preamp / att, else 0. */
+typedef struct ddc_autogain {
+    uint8_t stage, wait_reaction; /* autogain_stage, autogain_wait_reaction (trx_manager.c:35-36) */
+    uint8_t preamp, att;          /* TRX.Preamp, TRX.ATT as the search leaves them */
+} ddc_autogain;
+int ddc_autogain_step(ddc_autogain *st, int16_t adc_max_amplitude);
 /* S-meter extremes, AGC / ALC gain, CW decoder text (waits for the ctx stream). */
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
 

@@ -78,6 +78,8 @@ extern struct TRX_SETTINGS {
     uint16_t CW_GENERATOR_SHIFT_HZ;
     uint8_t FFT_Averaging;
     uint16_t SSB_HPF_pass;
+    bool AutoGain; /* settings.h:90 */
+    bool ATT, LPF, BPF;
 } TRX;
 
 /* trx_manager.h: transceiver state the path reads */
@@ -86,6 +88,7 @@ extern volatile bool TRX_ADC_OTR, TRX_DAC_OTR;
 extern volatile int16_t TRX_ADC_MINAMPLITUDE, TRX_ADC_MAXAMPLITUDE;
 VFO *CurrentVFO(void);    /* settings.c */
 uint8_t TRX_getMode(void); /* trx_manager.c */
+void TRX_DoAutoGain(void);  /* trx_manager.c:268: once a second, on TRX_ADC_MAXAMPLITUDE; sets TRX.Preamp / TRX.ATT */
 bool TRX_on_TX(void);      /* trx_manager.c:  ptt | tune | CAT ptt | key */
 
 /* fpga.h:12-31 */

@@ -863,3 +863,55 @@ void orc_fft_move_waterfall(orc_audio_t *s, int16_t freq_diff)
         }
     }
 }
+
+/* ---- auto-gain search ------------------------------------------------------------
+ * TRX_DoAutoGain, STM32/Src/trx_manager.c:268-356 (stage / wait counters :35-36),
+ * constants STM32/Src/settings.h:23-25 and trx_manager.h:9, db2rateV functions.c:262-265.
+ * st: {stage, wait_reaction, preamp, att}; written as the firmware writes it, case by case. */
+void orc_autogain_step(uint8_t *st, int16_t adc_max)
+{
+    uint8_t stage = st[0], wait = st[1];
+    const double att_rate = pow(10.0, (12 / 20.0)), pre_rate = pow(10.0, (20 / 20.0));
+    switch (stage) {
+    case 0:
+        st[2] = 0; st[3] = 1;
+        stage++; wait = 0;
+        break;
+    case 1:
+        if ((adc_max * att_rate) <= 1100) wait++;
+        else wait = 0;
+        if (wait >= 7) { stage++; wait = 0; }
+        break;
+    case 2:
+        st[2] = 0; st[3] = 0;
+        stage++; wait = 0;
+        break;
+    case 3:
+        if (adc_max > 1100) stage -= 3;
+        if ((adc_max * pre_rate / att_rate) <= 1100) wait++;
+        else wait = 0;
+        if (wait >= 7) { stage++; wait = 0; }
+        break;
+    case 4:
+        st[2] = 1; st[3] = 1;
+        stage++; wait = 0;
+        break;
+    case 5:
+        if (adc_max > 1100) stage -= 3;
+        if ((adc_max * att_rate) <= 1100) wait++;
+        else wait = 0;
+        if (wait >= 7) { stage++; wait = 0; }
+        break;
+    case 6:
+        st[2] = 1; st[3] = 0;
+        stage++; wait = 0;
+        break;
+    case 7:
+        if (adc_max > 1100) stage -= 3;
+        break;
+    default:
+        stage = 0;
+        break;
+    }
+    st[0] = stage; st[1] = wait;
+}

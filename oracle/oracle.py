@@ -406,3 +406,11 @@ class Audio:
         hts = np.zeros(256, np.uint8)
         lib().orc_fft_frame(self.buf, _p(spec), _p(bins), _p(row), _p(hts))
         return bins, row, hts
+
+
+def autogain_step(state, adc_max):
+    """TRX_DoAutoGain (trx_manager.c:268-356) on state = [stage, wait, preamp, att] (list of 4 ints, updated in place)."""
+    st = (C.c_uint8 * 4)(*state)
+    lib().orc_autogain_step(st, C.c_int16(int(adc_max)))
+    state[:] = list(st)
+    return state

@@ -15,7 +15,8 @@ class TrxSettings(C.Structure):
                 ("RF_Power", C.c_uint8), ("FM_SQL_threshold", C.c_uint8), ("RF_Gain", C.c_uint8),
                 ("FFT_Zoom", C.c_uint8), ("NotchFilter", C.c_bool), ("NotchFC", C.c_uint16), ("CWDecoder", C.c_bool),
                 ("FFT_Enabled", C.c_bool), ("CW_GENERATOR_SHIFT_HZ", C.c_uint16), ("FFT_Averaging", C.c_uint8),
-                ("SSB_HPF_pass", C.c_uint16)]
+                ("SSB_HPF_pass", C.c_uint16), ("AutoGain", C.c_bool), ("ATT", C.c_bool), ("LPF", C.c_bool),
+                ("BPF", C.c_bool)]
 
 
 class Legacy:
@@ -34,7 +35,7 @@ class Legacy:
         L.CWDecoder_Process.argtypes = [C.c_void_p]
         for f in ("FPGA_Init", "FPGA_fpgadata_iqclock", "FPGA_fpgadata_stuffclock", "processRxAudio", "processTxAudio",
                   "initAudioProcessor", "FFT_Init", "FFT_doFFT", "ddc_legacy_shutdown", "dc_filter", "DoAGC",
-                  "processNoiseReduction", "CWDecoder_Process"):
+                  "processNoiseReduction", "CWDecoder_Process", "TRX_DoAutoGain"):
             getattr(L, f).restype = None
         self.TRX = TrxSettings.in_dll(L, "TRX")
 

@@ -112,3 +112,61 @@ def test_library_exports_the_firmware_interface(ddc):
         assert must in names, must
     for n in names:
         assert hasattr(L, n), "missing export " + n
+
+
+def test_autogain_search_matches_oracle_and_the_firmware_story(ddc, orc):
+    """ddc_autogain_step against the restated TRX_DoAutoGain on random and scripted
+    amplitude sequences, and the walk the firmware comments describe."""
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        g, ref = ddc.AutoGain(), [0, 0, 0, 0]
+        amps = rng.choice([0, 30, 100, 250, 280, 400, 1000, 1099, 1100, 1101, 1500, 2047, -5], 200)
+        for a in amps:
+            before = ref[2:4]
+            orc.autogain_step(ref, a)
+            changed = g.step(a)
+            st = g.state
+            assert [st["stage"], st["wait_reaction"], int(st["preamp"]), int(st["att"])] == ref
+            assert changed == (before != ref[2:4])
+    # a quiet band: ATT first, then 7 calm seconds per step up to PREAMP without ATT
+    g = ddc.AutoGain()
+    seen = []
+    for _ in range(40):
+        g.step(20)
+        s = g.state
+        seen.append((s["preamp"], s["att"]))
+    assert seen[0] == (False, True) and seen[-1] == (True, False)
+    assert seen.index((False, False)) == 8 and seen.index((True, True)) == 16 and seen.index((True, False)) == 24
+    # a strong signal appears: one setting back
+    g.step(1500)
+    assert g.state["stage"] == 4
+    g.step(1500)
+    assert (g.state["preamp"], g.state["att"]) == (True, True)
+    # 276 * 10^(12/20) = 1098.8 <= 1100 counts as calm, 277 does not (stage 1)
+    g = ddc.AutoGain()
+    g.step(0)
+    for _ in range(6):
+        g.step(276)
+    assert g.state["wait_reaction"] == 6
+    g.step(277)
+    assert g.state["wait_reaction"] == 0 and g.state["stage"] == 1
+
+
+def test_legacy_autogain_drives_the_trx_fields(ddc):
+    """TRX_DoAutoGain of the firmware-style shim: host-only, works on TRX and TRX_ADC_MAXAMPLITUDE."""
+    import ctypes as C
+    from tests.legacy_binding import Legacy
+    fw = Legacy(ddc.lib())
+    amp = fw.var("TRX_ADC_MAXAMPLITUDE", C.c_int16)
+    fw.TRX.AutoGain = False
+    fw.TRX.Preamp, fw.TRX.ATT = True, False
+    fw.L.TRX_DoAutoGain()
+    assert (fw.TRX.Preamp, fw.TRX.ATT) == (True, False)  # feature off: untouched
+    fw.TRX.AutoGain = True
+    amp.value = 10
+    fw.L.TRX_DoAutoGain()
+    assert (fw.TRX.Preamp, fw.TRX.ATT, fw.TRX.LPF, fw.TRX.BPF) == (False, True, True, True)
+    for _ in range(8):
+        fw.L.TRX_DoAutoGain()
+    assert (fw.TRX.Preamp, fw.TRX.ATT) == (False, False)
+    fw.TRX.AutoGain = False

@@ -185,6 +185,19 @@ size_t ddc_legacy_dac_pop(uint16_t *dac, size_t n)
 
 VFO *CurrentVFO(void) { return TRX.current_vfo ? &TRX.VFO_B : &TRX.VFO_A; }
 uint8_t TRX_getMode(void) { return CurrentVFO()->Mode; }
+
+static ddc_autogain g_autogain;
+void TRX_DoAutoGain(void)
+{
+    if (!TRX.AutoGain) return;
+    TRX.LPF = true;
+    TRX.BPF = true;
+    g_autogain.preamp = TRX.Preamp;
+    g_autogain.att = TRX.ATT;
+    ddc_autogain_step(&g_autogain, TRX_ADC_MAXAMPLITUDE);
+    TRX.Preamp = g_autogain.preamp;
+    TRX.ATT = g_autogain.att;
+}
 bool TRX_on_TX(void) { return TRX_ptt_hard || TRX_ptt_cat || TRX_tune || TRX_getMode() == TRX_MODE_LOOPBACK; }
 
 uint32_t getPhraseFromFrequency(uint32_t freq)

@@ -1039,6 +1039,40 @@ int ddc_audio_smeter_dbm(ddc_ctx *ctx, int32_t channel, float *dbm)
     return 0;
 }
 
+int ddc_autogain_step(ddc_autogain *st, int16_t adc_max_amplitude)
+{
+    if (!st) return -EINVAL;
+    // trx_manager.c:268-356, the TRX.AutoGain branch; the thresholds are evaluated in double as there
+    const double att = pow(10.0, 12 / 20.0), pre = pow(10.0, 20 / 20.0); // db2rateV, functions.c:262-265
+    const double amp = (double)adc_max_amplitude, limit = 1100.0;
+    const uint8_t before_p = st->preamp, before_a = st->att;
+    auto quiet = [&](bool ok) {
+        if (ok) st->wait_reaction++;
+        else st->wait_reaction = 0;
+        if (st->wait_reaction >= 7) { st->stage++; st->wait_reaction = 0; }
+    };
+    switch (st->stage) {
+    case 0: st->preamp = 0; st->att = 1; st->stage++; st->wait_reaction = 0; break;
+    case 1: quiet(amp * att <= limit); break;
+    case 2: st->preamp = 0; st->att = 0; st->stage++; st->wait_reaction = 0; break;
+    case 3:
+        if (adc_max_amplitude > 1100) st->stage -= 3; // too much gain: one setting back (and still counts below)
+        quiet(amp * pre / att <= limit);
+        break;
+    case 4: st->preamp = 1; st->att = 1; st->stage++; st->wait_reaction = 0; break;
+    case 5:
+        if (adc_max_amplitude > 1100) st->stage -= 3;
+        quiet(amp * att <= limit);
+        break;
+    case 6: st->preamp = 1; st->att = 0; st->stage++; st->wait_reaction = 0; break;
+    case 7:
+        if (adc_max_amplitude > 1100) st->stage -= 3;
+        break;
+    default: st->stage = 0; break;
+    }
+    return st->preamp != before_p || st->att != before_a;
+}
+
 int ddc_audio_stage(ddc_ctx *ctx, int32_t channel, int stage, int arg, float *buf, int n)
 {
     int rc = check_channel(ctx, channel);

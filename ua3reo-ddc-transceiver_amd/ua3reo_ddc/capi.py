@@ -108,6 +108,7 @@ def lib():
     L.ddc_audio_update.argtypes = [vp, i32, vp]
     L.ddc_audio_smeter_dbm.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.ddc_fft_get_waterfall.argtypes = [vp, i32, vp]
+    L.ddc_autogain_step.argtypes = [vp, C.c_int16]
     L.ddc_fft_move_waterfall.argtypes = [vp, i32, i32]
     L.ddc_audio_stage.argtypes = [vp, i32, C.c_int, C.c_int, vp, C.c_int]
     L.ddc_audio_rx_process_dev.argtypes = [vp, vp, vp, sz, vp]
@@ -422,3 +423,21 @@ def parse_params(b):
     tx, pre, phi = C.c_int(), C.c_int(), C.c_uint32()
     lib().ddc_parse_params(_np_ptr(buf), C.byref(tx), C.byref(pre), C.byref(phi))
     return tx.value, pre.value, phi.value
+
+
+class AutoGain:
+    """ddc_autogain_step: the firmware's once-a-second preamp / attenuator search."""
+
+    def __init__(self):
+        self._st = (C.c_uint8 * 4)()
+
+    def step(self, adc_max_amplitude):
+        """Returns True when preamp / att changed."""
+        rc = lib().ddc_autogain_step(self._st, int(adc_max_amplitude))
+        if rc < 0:
+            raise DdcError("ddc_autogain_step failed: %d" % rc)
+        return bool(rc)
+
+    @property
+    def state(self):
+        return {"stage": self._st[0], "wait_reaction": self._st[1], "preamp": bool(self._st[2]), "att": bool(self._st[3])}
