@@ -292,25 +292,34 @@ __device__ __forceinline__ float lattice_reg(float (&g)[11], const float (&k)[11
 constexpr int kABiPitch = kABlock + 1; // LDS row pitch in floats: rows of neighbouring lanes start one bank apart
 
 /*
- * processRxAudio for every channel: thread = channel, sequential over the
- * n_frames / 192 blocks of the call.  spec_iq / voice_iq: [channel][n_frames][2]
- * int16; audio: [channel][n_frames][2] int32 (left = I, right = Q).
+ * processRxAudio for every channel, sequential over the n_frames / 192 blocks of
+ * the call.  spec_iq / voice_iq: [channel][n_frames][2] int16; audio:
+ * [channel][n_frames][2] int32 (left = I, right = Q).
  *
- * Everything that runs sample by sample in the firmware (DC blockers, gain, both
- * lattice pairs, demodulator, notch, S-meter) runs here in one pass with its
- * state in registers; the block of 192 demodulated samples that the block-wise
- * stages need (noise reduction, AGC peak and ramp, CW decoder) waits in LDS.
+ * A channel is a pair of neighbouring lanes: the I and the Q branch each run
+ * their DC blocker, gain and lattice filters (most of the arithmetic, and the two
+ * never meet before the demodulator) in a lane of their own and swap the
+ * filtered sample with one DPP move.  From there on both lanes hold both values
+ * and run the demodulator, notch and S-meter identically; the even lane alone
+ * owns the shared state, the block-wise stages and the stores.
+ *
+ * Everything that runs sample by sample in the firmware runs here in one pass
+ * with its state in registers; the block of 192 demodulated samples that the
+ * block-wise stages need (noise reduction, AGC peak and ramp, CW decoder) waits
+ * in LDS.
  */
 __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ states, uint32_t n_ch,
                                                    const int16_t *__restrict__ spec_iq,
                                                    const int16_t *__restrict__ voice_iq, uint32_t n_frames,
                                                    int32_t *__restrict__ audio)
 {
-    __shared__ float blockbuf[64 * kABiPitch];
-    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float blockbuf[32 * kABiPitch];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ch = gid >> 1, q = gid & 1u; // q = 0: I branch and owner of the channel, 1: Q branch
     if (ch >= n_ch) return;
+    const bool owner = q == 0;
     AudioState &s = states[ch];
-    float *bi = &blockbuf[threadIdx.x * kABiPitch];
+    float *bi = &blockbuf[(threadIdx.x >> 1) * kABiPitch];
     const ddc_audio_params p = s.p;
     const int m = p.mode;
     const bool use_spec = (m == DDC_MODE_IQ || m == DDC_MODE_NFM || m == DDC_MODE_WFM || m == DDC_MODE_AM);
@@ -334,10 +343,12 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
     for (int i = 0; i < 11; i++) { lk[i] = ddc_lpf_k[s.lpf_idx][i]; hk[i] = i < 6 ? ddc_hpf_k[s.hpf_idx][i] : 0.0f; }
 #pragma unroll
     for (int i = 0; i < 12; i++) { lv[i] = ddc_lpf_v[s.lpf_idx][i]; hv[i] = i < 7 ? ddc_hpf_v[s.hpf_idx][i] : 0.0f; }
-    float ghi[11], ghq[11], gli[11], glq[11];
+    float *hpf_g = q ? s.hpf_q.g : s.hpf_i.g, *lpf_g = q ? s.lpf_q.g : s.lpf_i.g;
+    float gh[11], gl[11]; // this branch's lattice states
 #pragma unroll
-    for (int i = 0; i < 11; i++) { ghi[i] = s.hpf_i.g[i]; ghq[i] = s.hpf_q.g[i]; gli[i] = s.lpf_i.g[i]; glq[i] = s.lpf_q.g[i]; }
-    float dx0 = s.dc_x[0], dy0 = s.dc_y[0], dx1 = s.dc_x[1], dy1 = s.dc_y[1];
+    for (int i = 0; i < 11; i++) { gh[i] = hpf_g[i]; gl[i] = lpf_g[i]; }
+    float dx = s.dc_x[q], dy = s.dc_y[q];
+    const uint32_t half_off = ((q ^ (swap ? 1u : 0u)) & 1u) * 16u; // the half of a packed word this branch filters
     float nc[5], nd[2] = { s.notch_d[0], s.notch_d[1] };
 #pragma unroll
     for (int i = 0; i < 5; i++) nc[i] = s.notch_c[i];
@@ -358,17 +369,19 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
             int32_t out[32];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t v = in[k];
-                float fi = (float)(int16_t)(v & 0xFFFFu), fq = (float)((int32_t)v >> 16);
-                if (swap) { const float t = fi; fi = fq; fq = t; }
-                { const float d = fi - dx0; const float a = A1 * dy0; const float o = d + a; dx0 = fi; dy0 = o; fi = o * rf_gain; }
-                { const float d = fq - dx1; const float a = A1 * dy1; const float o = d + a; dx1 = fq; dy1 = o; fq = o * rf_gain; }
+                float f = (float)(int)__builtin_amdgcn_sbfe(in[k], half_off, 16u);
+                { const float d = f - dx; const float a = A1 * dy; const float o = d + a; dx = f; dy = o; f = o * rf_gain; }
                 if (chain) {
-                    if (hpf) { fi = lattice_reg<6>(ghi, hk, hv, fi); fq = lattice_reg<6>(ghq, hk, hv, fq); }
+                    if (hpf) f = lattice_reg<6>(gh, hk, hv, f);
                     if (lpf) {
-                        if (lpf_n == 11) { fi = lattice_reg<11>(gli, lk, lv, fi); fq = lattice_reg<11>(glq, lk, lv, fq); }
-                        else { fi = lattice_reg<7>(gli, lk, lv, fi); fq = lattice_reg<7>(glq, lk, lv, fq); }
+                        if (lpf_n == 11) f = lattice_reg<11>(gl, lk, lv, f);
+                        else f = lattice_reg<7>(gl, lk, lv, f);
                     }
+                }
+                // the other branch's sample, from the neighbouring lane (quad_perm 1,0,3,2)
+                const float fo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, true));
+                float fi = q ? fo : f, fq = q ? f : fo;
+                if (chain) {
                     if (ssb_l) fi = fi - fq;
                     else if (ssb_u) fi = fi + fq;
                     else if (am) {
@@ -401,10 +414,10 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
                 if (fq > sm_max) sm_max = fq;
                 if (fi < sm_min) sm_min = fi;
                 if (fq < sm_min) sm_min = fq;
-                if (chain) bi[i0 + k] = fi;
+                if (chain) { if (owner) bi[i0 + k] = fi; }
                 else { out[2 * k] = f2i_sat(fi * vol); out[2 * k + 1] = f2i_sat(fq * vol); }
             }
-            if (!chain) {
+            if (!chain && owner) {
 #pragma unroll
                 for (int k = 0; k < 8; k++)
                     reinterpret_cast<int4 *>(dst + 2 * (b0 + i0))[k] = make_int4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
                 if (fm_cnt >= 50) fm_cnt = 0;
             }
         }
-        if (chain) {
+        if (chain && owner) {
             if (p.dnr)
                 for (int sb = 0; sb < kABlock / kASub; sb++) {
                     float *x = bi + sb * kASub;
@@ -449,8 +462,9 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
         blocks++;
     }
 #pragma unroll
-    for (int i = 0; i < 11; i++) { s.hpf_i.g[i] = ghi[i]; s.hpf_q.g[i] = ghq[i]; s.lpf_i.g[i] = gli[i]; s.lpf_q.g[i] = glq[i]; }
-    s.dc_x[0] = dx0; s.dc_y[0] = dy0; s.dc_x[1] = dx1; s.dc_y[1] = dy1;
+    for (int i = 0; i < 11; i++) { hpf_g[i] = gh[i]; lpf_g[i] = gl[i]; }
+    s.dc_x[q] = dx; s.dc_y[q] = dy;
+    if (!owner) return; // what follows is identical in both lanes
     s.notch_d[0] = nd[0]; s.notch_d[1] = nd[1];
     s.smeter_max = sm_max; s.smeter_min = sm_min;
     s.fm_lpf_prev = fm_lpf; s.fm_hpf_a = fm_ha; s.fm_hpf_b = fm_hb; s.fm_i_prev = fm_ip; s.fm_q_prev = fm_qp;

@@ -813,7 +813,7 @@ int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const uint32_t nch = ctx->cfg.n_channels;
-    hipLaunchKernelGGL(ddc::ddc_audio_rx, dim3((nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, nch, spec_iq,
+    hipLaunchKernelGGL(ddc::ddc_audio_rx, dim3((2 * nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, nch, spec_iq,
                        voice_iq, (uint32_t)n_frames, audio_lr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
