@@ -1,4 +1,4 @@
-// Probe of v_mfma_i32_32x32x32_i8 operand layouts on gfx950: checks
+// Probe of v_mfma_i32_32x32x32_i8 operand layouts on gfx950 (hipcc --offload-arch=gfx950 -O2 -o mfma_probe mfma_probe.hip): checks
 //   C[i][j] = sum_{h<2} sum_{t<16} A(lane i + 32 h, byte t) * B(lane j + 32 h, byte t)
 // with C element (i, j) in lane j + 32 * ((i / 4) % 2), register 4 * (i / 8) + i % 4.
 #include <hip/hip_runtime.h>
