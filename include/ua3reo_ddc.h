@@ -107,6 +107,13 @@ int ddc_tx_set_phase(ddc_ctx *ctx, int32_t channel, uint32_t phase22);
 int ddc_sync(ddc_ctx *ctx);
 /* The HIP stream of the ctx (a hipStream_t), for callers that time or chain work. */
 void *ddc_stream(ddc_ctx *ctx);
+/* Run the ctx on a stream of the caller's (a hipStream_t; NULL = back to the ctx's own
+ * stream): every later call enqueues there, so work the caller queued on that stream
+ * before (filling the input) and after (reading the output) is ordered without an event.
+ * Waits for what the ctx still has in flight on its previous stream.  The caller keeps
+ * ownership of its stream and must not destroy it while the ctx uses it.  No counterpart
+ * in the reference (the firmware has one flow of control). */
+int ddc_set_stream(ddc_ctx *ctx, void *hip_stream);
 
 /* Timing taps (the reference's analogue is STM32/Src/profiler.c:21-88): when
  * enabled, every ddc_rx_process_dev call records HIP events on the ctx stream

@@ -232,6 +232,14 @@ def test_state_save_restore_resumes_bit_exact(ddc, orc):
     assert np.array_equal(a1, a2)
     with pytest.raises(ddc.DdcError):
         ddc.Ddc(3).state_restore(blob)
+    # a blob of another layout version (header word 1), a damaged magic and a short blob are refused
+    for damage in ((4, 1), (0, 0xFF)):
+        bad = blob.copy()
+        bad[damage[0]] = damage[1]
+        with pytest.raises(ddc.DdcError):
+            ddc.Ddc(2).state_restore(bad)
+    with pytest.raises(ddc.DdcError):
+        ddc.Ddc(2).state_restore(blob[:-8])
 
 
 def test_many_channels_few_blocks(ddc, orc):
@@ -337,3 +345,39 @@ def test_both_ingest_kernels_agree(ddc, orc, monkeypatch, n_ch, samples, pitch_e
     for c in (0, 1, n_ch // 2, n_ch - 1):
         ws, wv = orc.RxChain(int(phis[c])).run(adc[c])
         assert np.array_equal(res["mm"][0][c], ws) and np.array_equal(res["mm"][1][c], wv), c
+
+
+def test_caller_stream_orders_producer_and_consumer(ddc, orc):
+    """ddc_set_stream: the ctx enqueues on the caller's stream, so a fill queued there
+    before the call and a copy queued after it need no synchronisation in between."""
+    torch = pytest.importorskip("torch")
+    nch, n = 32, 1 << 18
+    rb = n // 2 * 3
+    phis = [(131 * c + 9000 * c * c + 11) & 0x3FFFFF for c in range(nch)]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    src = torch.randint(0, 256, (4, nch, rb), dtype=torch.uint8, device="cuda", generator=g)
+    st = torch.cuda.Stream()
+    d = ddc.Ddc(nch)
+    d.tune_many(phis)
+    d.set_stream(st.cuda_stream)
+    assert d.stream() == st.cuda_stream
+    adc = torch.empty((nch, rb), dtype=torch.uint8, device="cuda")
+    spec = torch.zeros((nch, n // 1024, 2), dtype=torch.int16, device="cuda")
+    voice = torch.zeros_like(spec)
+    torch.cuda.synchronize()
+    got = []
+    with torch.cuda.stream(st):
+        for k in range(4):
+            adc.copy_(src[k])                      # producer on st
+            d.rx_process_dev(adc.data_ptr(), rb, n, spec.data_ptr(), voice.data_ptr())
+            got.append((spec.clone(), voice.clone()))  # consumer on st
+    st.synchronize()
+    host = src.cpu().numpy()
+    for c in (0, 17, 31):
+        x = np.concatenate([ddc.unpack_adc12(host[k, c], n) for k in range(4)])
+        ws, wv = orc.RxChain(phis[c]).run(x)
+        assert np.array_equal(np.concatenate([s[c].cpu().numpy() for s, _ in got]), ws)
+        assert np.array_equal(np.concatenate([v[c].cpu().numpy() for _, v in got]), wv)
+    d.set_stream(None)
+    assert d.stream() != st.cuda_stream
+    d.close()

@@ -21,7 +21,8 @@
 
 struct ddc_ctx {
     ddc_config cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where the calls enqueue: own_stream unless ddc_set_stream chose another
+    hipStream_t own_stream = nullptr;
     std::string err;
     // device state, per channel
     uint32_t *d_acc = nullptr;   // NCO phase << 10
@@ -228,7 +229,8 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         }                                                                                    \
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
-    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
     const size_t nch = cfg->n_channels;
     CREATE_TRY(hipMalloc(&ctx->d_acc, nch * 4));
     CREATE_TRY(hipMalloc(&ctx->d_phi, nch * 4));
@@ -340,7 +342,7 @@ void ddc_destroy(ddc_ctx *ctx)
     for (auto &e3 : ctx->ev)
         for (auto &e : e3)
             if (e) (void)hipEventDestroy(e);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -650,6 +652,15 @@ int ddc_sync(ddc_ctx *ctx)
 }
 
 void *ddc_stream(ddc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int ddc_set_stream(ddc_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return -EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
 
 int ddc_profile_enable(ddc_ctx *ctx, int on)
 {

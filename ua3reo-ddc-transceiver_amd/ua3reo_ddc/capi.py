@@ -83,6 +83,7 @@ def lib():
     L.ddc_sync.argtypes = [vp]
     L.ddc_stream.argtypes = [vp]
     L.ddc_stream.restype = vp
+    L.ddc_set_stream.argtypes = [vp, vp]
     L.ddc_profile_enable.argtypes = [vp, C.c_int]
     L.ddc_profile_collect.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u32)]
     L.ddc_pack_rx_frames.argtypes = [vp, vp, sz, vp]
@@ -347,6 +348,10 @@ class Ddc:
     def state_restore(self, blob):
         b = np.ascontiguousarray(blob, dtype=np.uint8)
         self._check(self._L.ddc_state_restore(self._h, _np_ptr(b), b.size))
+
+    def set_stream(self, hip_stream):
+        """Enqueue on the caller's hipStream_t (an int handle, e.g. torch.cuda.current_stream().cuda_stream); None = own stream."""
+        self._check(self._L.ddc_set_stream(self._h, hip_stream))
 
     def sync(self):
         self._check(self._L.ddc_sync(self._h))
