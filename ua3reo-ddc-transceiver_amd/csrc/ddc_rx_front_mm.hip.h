@@ -40,7 +40,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kMmThreads = kFrontThreads;
 constexpr int kMmSteps = 32;             // 16-sample steps per block
-constexpr int kMmTabRows = kMmSteps + 1; // + one all-zero row (lanes without a column, and the last prefetch)
+constexpr int kMmTabRows = kMmSteps;     // one row of 16 columns x 16 bytes per step; column 15 is zero in every row
 constexpr int kMmLastD = 506;            // distance of the block's first sample from its window's end
 
 // column of byte plane p (0 = least significant) of weight e
