@@ -166,11 +166,12 @@ class RxChain(_State):
 
 
 def build_native_variant(out_dir):
-    """The same sources built for the host this runs on (gcc -O3 -march=native), for
+    """The same sources built for the host this runs on (gcc -O3 -march=native, widest vectors), for
     timing the CPU baseline; returns a CDLL of its own, ready to use."""
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libddc_oracle_native.so")
-    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-shared", "-o", so,
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-mprefer-vector-width=512", "-fPIC", "-std=c11",
+                           "-ffp-contract=off", "-shared", "-o", so,
                            os.path.join(_HERE, "ddc_oracle.c"), os.path.join(_HERE, "audio_oracle.c"), "-lm"])
     L = C.CDLL(so)
     L.orc_init.restype = None
@@ -178,15 +179,16 @@ def build_native_variant(out_dir):
     return L
 
 
-def rx_chain_packed(packed, row_bytes, n_channels, n, phi, L=None):
-    """Fresh-state RX chain over packed 12-bit rows; returns spec, voice [ch][frame][2]."""
+def rx_chain_packed(packed, row_bytes, n_channels, n, phi, L=None, fast=False):
+    """Fresh-state RX chain over packed 12-bit rows; returns spec, voice [ch][frame][2].
+    fast: the window form of mixer + rx_cic (orc_fast_rx_front_run) instead of the clock-level model."""
     packed = np.ascontiguousarray(packed, dtype=np.uint8)
     phi = np.ascontiguousarray(phi, dtype=np.uint32)
     nf = n // 1024
     spec = np.zeros((n_channels, nf, 2), np.int16)
     voice = np.zeros((n_channels, nf, 2), np.int16)
-    (L or lib()).orc_rx_chain_packed(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_channels),
-                              C.c_size_t(n), _p(phi), _p(spec), _p(voice))
+    f = (L or lib()).orc_fast_rx_chain_packed if fast else (L or lib()).orc_rx_chain_packed
+    f(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_channels), C.c_size_t(n), _p(phi), _p(spec), _p(voice))
     return spec, voice
 
 
@@ -414,3 +416,15 @@ def autogain_step(state, adc_max):
     lib().orc_autogain_step(st, C.c_int16(int(adc_max)))
     state[:] = list(st)
     return state
+
+
+def fast_rx_front(phi, adc):
+    """orc_fast_rx_front_run: window form of mixer + rx_cic from reset; returns (I, Q) int16 arrays of n // 512 outputs."""
+    adc = _i16(adc)
+    n = adc.size
+    oi = np.zeros(n // 512, np.int16)
+    oq = np.zeros(n // 512, np.int16)
+    f = lib().orc_fast_rx_front_run
+    f.restype = C.c_size_t
+    f(C.c_uint32(int(phi)), _p(adc), C.c_size_t(n), _p(oi), _p(oq))
+    return oi, oq

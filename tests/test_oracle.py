@@ -207,3 +207,29 @@ def test_bus_frames(orc):
         [0xFF, 0xFE, 0x12, 0x34, 0x80, 0x00, 0x7F, 0xFF])
     assert orc.unpack_tx_frame(bytes([0x80, 0x01, 0x12, 0x34])) == (0x1234, -32767)
     assert orc.parse_params(bytes([0b1100, 0x09, 0x3E, 0xAB])) == (1, 1, 0x093EAB)
+
+
+def test_window_form_cpu_front_equals_clock_level_model(orc):
+    """orc_fast_rx_front_run (the CPU baseline the benchmark times) against the
+    clock-level mixer + rx_cic model, from reset: random full scale, the product
+    that wraps at every sample, lengths that do not fill the 16 lanes."""
+    rng = np.random.default_rng(77)
+    cases = [(512 * 40, 605867, None), (512 * 3, 12345, None), (512, 4194303, None), (512 * 17, 3 << 20, -2048),
+             (512 * 33, 1, 2047), (1024 * 48, 2097152, None), (512 * 16, 0, -2048)]
+    for n, phi, fill in cases:
+        x = rng.integers(-2048, 2048, n).astype(np.int16) if fill is None else np.full(n, fill, np.int16)
+        wi, wq = orc.RxFront(phi).run(x)
+        gi, gq = orc.fast_rx_front(phi, x)
+        assert len(wi) == n // 512
+        assert np.array_equal(gi, wi) and np.array_equal(gq, wq), (n, phi)
+
+
+def test_window_form_cpu_chain_equals_clock_level_chain(orc):
+    rng = np.random.default_rng(78)
+    n, nch = 1024 * 40, 3
+    xs = [rng.integers(-2048, 2048, n).astype(np.int16) for _ in range(nch)]
+    phis = [605867, 31337, 4000000]
+    packed = np.concatenate([orc.pack12(x) for x in xs])
+    a = orc.rx_chain_packed(packed, n // 2 * 3, nch, n, phis)
+    b = orc.rx_chain_packed(packed, n // 2 * 3, nch, n, phis, fast=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
