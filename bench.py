@@ -205,6 +205,7 @@ def main():
     computed = [torch.cuda.Event(), torch.cuda.Event()]
     gathered_ev = [torch.cuda.Event(), torch.cuda.Event()]
     step_no = [0]
+    gather_times = None  # (start, end) events of every all-gather of the timed region
     torch.cuda.synchronize()
 
     def step():
@@ -220,7 +221,13 @@ def main():
             computed[b].record(ext)
             comm.wait_event(computed[b])
             with torch.cuda.stream(comm):
+                if gather_times is not None:
+                    t_a, t_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t_a.record(comm)
                 dist.all_gather_into_tensor(gathered.view(torch.uint8), o.view(torch.uint8))
+                if gather_times is not None:
+                    t_b.record(comm)
+                    gather_times.append((t_a, t_b))
                 gathered_ev[b].record(comm)
 
     # parity spot check before any timing: first step from power-on state vs the oracle
@@ -252,6 +259,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if do_gather:
+        gather_times = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -313,7 +322,12 @@ def main():
                 "algorithmic_bytes_per_launch": BYTES_PER_CHANNEL_SAMPLE * nch * S,
             },
         }
-        if not args.no_cpu_baseline:
+        if gather_times:
+            g_ms = sum(a.elapsed_time(b) for a, b in gather_times) / len(gather_times)
+            res["config"]["all_gather"] = {"avg_ms": round(g_ms, 4), "bytes_per_rank": int(outs[0].numel() * 2),
+                                           "share_of_step": round(g_ms / (dt / args.steps * 1e3), 4),
+                                           "note": "on a second stream, overlapped with the next step's compute"}
+        if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)
             v, one, sample = cpu_baseline(threads)
             res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": threads,
