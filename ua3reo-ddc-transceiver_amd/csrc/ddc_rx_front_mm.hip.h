@@ -25,8 +25,8 @@
  * sums, the local dot products and the 5x5 basis change of ddc_rx_front are gone;
  * per sample the vector ALU is left with the NCO, the mixer and three byte
  * shuffles.  The five samples before a block (they open its window, d = 507..511)
- * still arrive from the neighbouring thread and enter through a small dot
- * product; the last five of the block carry zero weight.
+ * arrive from the neighbouring thread at the end and take one more step of the
+ * matrix instruction; the last five of the block carry zero weight.
  *
  * Output records, carries and every bit of the result are those of ddc_rx_front.
  */
@@ -40,17 +40,18 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kMmThreads = kFrontThreads;
 constexpr int kMmSteps = 32;             // 16-sample steps per block
-constexpr int kMmTabRows = kMmSteps;     // one row of 16 columns x 16 bytes per step; column 15 is zero in every row
+constexpr int kMmTabRows = kMmSteps + 1; // one row of 16 columns x 16 bytes per step (column 15 is zero in every row)
+                                         // + the row of the five samples before the block
 constexpr int kMmLastD = 506;            // distance of the block's first sample from its window's end
 
 // column of byte plane p (0 = least significant) of weight e
 __host__ __device__ constexpr int mm_col(int e, int p) { return e * (e + 1) / 2 + p; }
 
-// 128 * sum_{d=0..506} C(d + e, e) = 128 * C(507 + e, e + 1): what the low sample plane, fed as
+// 128 * sum_{d=0..511} C(d + e, e) = 128 * C(512 + e, e + 1): what the low sample plane, fed as
 // (byte ^ 0x80) = byte - 128, leaves out of every moment
 __host__ __device__ constexpr unsigned long long mm_low_plane_bias(int e)
 {
-    return 128ull * (unsigned long long)binom_gen(kMmLastD + 1 + e, e + 1);
+    return 128ull * (unsigned long long)binom_gen(kBlk + e, e + 1);
 }
 
 // weight table for the B operand: [kMmTabRows][16 columns][16 sample bytes]
@@ -72,6 +73,19 @@ inline bool build_mm_table(uint8_t *tab /* kMmTabRows * 256 bytes */)
                 if (v != 0) return false;
             }
         }
+    // last row: the five samples before the block sit in byte slots 11..15 (d = 511..507)
+    for (int t = 11; t < 16; t++) {
+        const int d = kBlk - 1 - (t - 11);
+        for (int e = 0; e < 5; e++) {
+            long long v = binom_gen(d + e, e);
+            for (int p = 0; p <= e; p++) {
+                const int dig = (int)(((v + 128) & 255) - 128);
+                v = (v - dig) / 256;
+                tab[(kMmSteps * 16 + mm_col(e, p)) * 16 + t] = (uint8_t)(int8_t)dig;
+            }
+            if (v != 0) return false;
+        }
+    }
     return true;
 }
 
@@ -110,25 +124,6 @@ __device__ __forceinline__ void mm_step(const unsigned (&pk)[8], const v4i bw, v
     acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, bw, acc_lo, 0, 0, 0);
 }
 
-// the five samples before the block (high half of pk[0], pk[1], pk[2]; the newest is d = 507):
-// B[e] += sum_i mu_i * C(506 + e - i, e - i),  mu_i = sum_c C(c + i, i) * sample(d = 507 + c)
-__device__ __forceinline__ void mm_head5(const unsigned (&pk)[3], unsigned long long (&B)[5])
-{
-    int mu[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-        const unsigned wa = pack_w(0, (int)binom_gen(4 + i, i));
-        const unsigned wb = pack_w((int)binom_gen(3 + i, i), (int)binom_gen(2 + i, i));
-        const unsigned wc = pack_w((int)binom_gen(1 + i, i), 1);
-        mu[i] = dot2(pk[2], wc, dot2(pk[1], wb, dot2(pk[0], wa, 0)));
-    }
-#pragma unroll
-    for (int e = 0; e < 5; e++)
-#pragma unroll
-        for (int i = 0; i <= e; i++)
-            B[e] += (unsigned long long)((long long)mu[i] * binom_gen(kMmLastD + e - i, e - i));
-}
-
 __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void ddc_rx_front_mm(
     const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t total_blocks,
     const uint32_t *__restrict__ acc0, const uint32_t *__restrict__ phi32v,
@@ -139,11 +134,13 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3
     __shared__ uint4 lines[8 * kMmThreads];
     // weight rows of the current and of the next line period (at most 6 steps each), see below
     __shared__ uint4 wbuf[2][6 * 16];
+    __shared__ uint4 whead[16]; // the row of the five samples before the block
 
     const uint32_t tid = threadIdx.x;
     const uint32_t g0 = blockIdx.x * kMmThreads;
     for (uint32_t i = tid; i < 2048; i += kMmThreads) tab[i] = nco_tab[i];
     if (tid < 4 * 16) wbuf[0][tid] = mm_tab[tid]; // steps 0..3
+    else if (tid < 5 * 16) whead[tid - 4 * 16] = mm_tab[kMmSteps * 16 + tid - 4 * 16];
 
     // staging sources, as in ddc_rx_front
     const uint32_t lane = tid & 63u, wave_base = tid & ~63u;
@@ -312,6 +309,14 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         }
         __syncthreads(); // the exchange area is reused below
     }
+    {
+        // one more step for them: byte slots 10..15 (slot 10, the sixth sample back, has weight zero)
+        const uint4 hw = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(whead) + wlane);
+        const v4i bw = { (int)hw.x, (int)hw.y, (int)hw.z, (int)hw.w };
+        const unsigned hi_[8] = { 0, 0, 0, 0, 0, pki[0], pki[1], pki[2] }, hq_[8] = { 0, 0, 0, 0, 0, pkq[0], pkq[1], pkq[2] };
+        mm_step(hi_, bw, aih, ail);
+        mm_step(hq_, bw, aqh, aql);
+    }
 
     // Accumulator register r of lane l is row i = 8 (r / 4) + r % 4 + 4 (l / 32) of column
     // j = l % 32, i.e. column j % 16 of window i + 32 (j / 16).  Every wave transposes its two
@@ -349,7 +354,6 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3
             }
             B[e] = acc;
         }
-        mm_head5(br ? pkq : pki, B);
     }
 
     if (!active) return;
