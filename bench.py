@@ -149,6 +149,9 @@ def main():
                          "--samples 4194304)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--shared-stream", action="store_true",
+                    help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
+                         "reported apart from the headline: the ADC bytes then come from L2, not HBM")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU; "
                          "needs a torch.distributed launch)")
@@ -183,7 +186,9 @@ def main():
     nf = S // 1024
     rb = S // 2 * 3
     chan0 = rank * nch
-    adc = synth_rows(nch, S, chan0, dev, 0x5EED0000 + rank)
+    shared = args.shared_stream
+    adc = synth_rows(1 if shared else nch, S, chan0, dev, 0x5EED0000 + rank)
+    pitch = 0 if shared else rb
     # [buffer][SPEC|VOICE][channel][frame][I,Q]; two buffers so that the gather of
     # step k overlaps the compute of step k+1
     outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
@@ -214,7 +219,7 @@ def main():
         o = outs[b]
         if do_gather and step_no[0] > 2:
             ext.wait_event(gathered_ev[b])  # the gather that last read this buffer
-        ctx.rx_process_dev(adc.data_ptr(), rb, S, o[0].data_ptr(), o[1].data_ptr())
+        ctx.rx_process_dev(adc.data_ptr(), pitch, S, o[0].data_ptr(), o[1].data_ptr())
         if with_fft:
             ctx.fft_process_dev(o[0].data_ptr(), nf, fft_bins.data_ptr(), fft_rows.data_ptr())
         if do_gather:
@@ -239,10 +244,10 @@ def main():
         chk_ctx.tune_many(phis)
         chk_out = torch.zeros((2, nch, ns // 1024, 2), dtype=torch.int16, device=dev)
         torch.cuda.synchronize()
-        chk_ctx.rx_process_dev(adc.data_ptr(), rb, ns, chk_out[0].data_ptr(), chk_out[1].data_ptr())
+        chk_ctx.rx_process_dev(adc.data_ptr(), pitch, ns, chk_out[0].data_ptr(), chk_out[1].data_ptr())
         chk_ctx.sync()
         for c in sorted({0, nch // 2, nch - 1}):
-            x = ua3reo_ddc.unpack_adc12(adc[c, : ns // 2 * 3].cpu().numpy(), ns)
+            x = ua3reo_ddc.unpack_adc12(adc[0 if shared else c, : ns // 2 * 3].cpu().numpy(), ns)
             os_, ov_ = oracle.RxChain(phis[c]).run(x)
             if not (np.array_equal(chk_out[0, c].cpu().numpy(), os_) and
                     np.array_equal(chk_out[1, c].cpu().numpy(), ov_)):
@@ -299,7 +304,8 @@ def main():
             "config": {
                 "workload": "%s: %d channels x %d ADC samples per step, "
                             "full FPGA RX chain (NCO+mixer+rx_cic+rx_ciccomp+rx_hilb/delay) to SPEC+VOICE int16 I/Q%s"
-                            % ("per-GPU shard of BASELINE config 5" if not with_fft else "BASELINE config 3 shape",
+                            % (("shared-stream fan-out (one ADC row, every channel its own tuning)" if shared else
+                                "per-GPU shard of BASELINE config 5") if not with_fft else "BASELINE config 3 shape",
                                nch, S, " + 512-point FFT panadapter rows" if with_fft else ""),
                 "channels_per_gpu": nch,
                 "samples_per_channel": S,
@@ -316,7 +322,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(nch, S),
+                "traffic": None if shared else measured_traffic(nch, S),
                 "avg_launch_ms": round(front_avg_ms, 4),
                 "rest_of_call_ms": round(tail_ms / max(1, ncalls), 4),
                 "algorithmic_bytes_per_launch": BYTES_PER_CHANNEL_SAMPLE * nch * S,

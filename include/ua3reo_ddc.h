@@ -71,6 +71,8 @@ int ddc_rx_get_phase(ddc_ctx *ctx, int32_t channel, uint32_t *phase22);
  *   adc12          packed signed 12-bit words, two per three bytes (b0=s0[7:0],
  *                  b1=s0[11:8]|s1[3:0]<<4, b2=s1[11:4]); one row per channel,
  *                  rows row_bytes apart (row_bytes a multiple of 16)
+ *                  row_bytes = 0: one ADC stream shared by every channel (the
+ *                  reference's case: one converter, here fanned out to N tunings)
  *   samples        ADC samples per channel in this call, a multiple of 1024
  *   spec_iq        [channel][samples/1024][2] int16: SPEC_I, SPEC_Q
  *   voice_iq       [channel][samples/1024][2] int16: VOICE_I, VOICE_Q

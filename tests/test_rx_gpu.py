@@ -381,3 +381,34 @@ def test_caller_stream_orders_producer_and_consumer(ddc, orc):
     d.set_stream(None)
     assert d.stream() != st.cuda_stream
     d.close()
+
+
+def test_shared_adc_stream_fans_out_to_all_channels(ddc, orc):
+    """row_bytes = 0: every channel mixes the same ADC row with its own tuning word
+    (one converter, many receivers), through both entry points and both ingest kernels'
+    addressing (many channels per wave)."""
+    torch = pytest.importorskip("torch")
+    n_ch, samples = 130, 1024 * 6
+    rng = np.random.default_rng(91)
+    x = rng.integers(-2048, 2048, 2 * samples).astype(np.int16)
+    phis = rng.integers(0, 1 << 22, n_ch).astype(np.uint32)
+    d = ddc.Ddc(n_ch)
+    d.tune_many(phis)
+    outs = [d.rx_process(ddc.pack_adc12(x[k * samples:(k + 1) * samples])[None, :], samples, row_bytes=0)
+            for k in range(2)]
+    spec = np.concatenate([o[0] for o in outs], axis=1)
+    voice = np.concatenate([o[1] for o in outs], axis=1)
+    assert spec.shape == (n_ch, 2 * samples // 1024, 2)
+    for c in (0, 1, 63, 64, 129):
+        ws, wv = orc.RxChain(int(phis[c])).run(x)
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+    # device pointers
+    e = ddc.Ddc(n_ch)
+    e.tune_many(phis)
+    row = torch.from_numpy(ddc.pack_adc12(x[:samples])).cuda()
+    s2 = torch.zeros((n_ch, samples // 1024, 2), dtype=torch.int16, device="cuda")
+    v2 = torch.zeros_like(s2)
+    torch.cuda.synchronize()
+    e.rx_process_dev(row.data_ptr(), 0, samples, s2.data_ptr(), v2.data_ptr())
+    e.sync()
+    assert np.array_equal(s2.cpu().numpy(), outs[0][0]) and np.array_equal(v2.cpu().numpy(), outs[0][1])

@@ -452,7 +452,8 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     if (!adc12 || !spec_iq || !voice_iq) return fail(ctx, -EINVAL, "null buffer");
     if (samples % DDC_DECIMATION) return fail(ctx, -EINVAL, "samples must be a multiple of 1024");
     if (row_bytes % 16 || ((uintptr_t)adc12 % 16)) return fail(ctx, -EINVAL, "ADC rows must be 16-byte aligned");
-    if (row_bytes < samples / 2 * 3) return fail(ctx, -EINVAL, "row_bytes smaller than one row of samples");
+    // row_bytes = 0: one ADC stream shared by every channel (all rows are the same row)
+    if (row_bytes && row_bytes < samples / 2 * 3) return fail(ctx, -EINVAL, "row_bytes smaller than one row of samples");
     const uint64_t n_blk64 = samples / 512;
     const uint64_t total64 = n_blk64 * ctx->cfg.n_channels;
     if (total64 >= (1ull << 31)) return fail(ctx, -EINVAL, "more than 2^31 blocks of 512 samples in one call");
@@ -475,8 +476,8 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
     uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
-    // ddc_rx_front_mm addresses the 64 blocks of a wave with 32-bit offsets from the first one
-    const bool near_rows = (unsigned long long)(64u / n_blk + 2u) * row_bytes < (1ull << 32);
+    // ddc_rx_front_mm addresses the 64 blocks of a wave with 32-bit offsets from the start of the first one's row
+    const bool near_rows = (unsigned long long)(64u / n_blk + 2u) * row_bytes + (unsigned long long)n_blk * 768u < (1ull << 32);
     if (ctx->front_dot2 || !near_rows)
         ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
             adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
@@ -515,9 +516,10 @@ int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t 
     if (samples % DDC_DECIMATION) return fail(ctx, -EINVAL, "samples must be a multiple of 1024");
     const size_t nch = ctx->cfg.n_channels;
     const size_t need_row = samples / 2 * 3;
-    if (row_bytes < need_row) return fail(ctx, -EINVAL, "row_bytes smaller than one row of samples");
+    if (row_bytes && row_bytes < need_row) return fail(ctx, -EINVAL, "row_bytes smaller than one row of samples");
     const size_t drow = (need_row + 255) / 256 * 256;
-    const size_t in_bytes = drow * nch;
+    const size_t in_rows = row_bytes ? nch : 1; // row_bytes = 0: one shared ADC stream
+    const size_t in_bytes = drow * in_rows;
     const size_t out_elems = nch * (samples / DDC_DECIMATION) * 2;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     if (in_bytes > ctx->in_cap) {
@@ -532,8 +534,9 @@ int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t 
         HIP_TRY(ctx, hipMalloc(&ctx->d_out, out_elems * 2 * sizeof(int16_t)));
         ctx->out_cap = out_elems * 2;
     }
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_in, drow, adc12, row_bytes, need_row, nch, hipMemcpyHostToDevice, ctx->stream));
-    int rc = ddc_rx_process_dev(ctx, ctx->d_in, drow, samples, ctx->d_out, ctx->d_out + out_elems);
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_in, drow, adc12, row_bytes ? row_bytes : need_row, need_row, in_rows,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    int rc = ddc_rx_process_dev(ctx, ctx->d_in, row_bytes ? drow : 0, samples, ctx->d_out, ctx->d_out + out_elems);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(spec_iq, ctx->d_out, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(voice_iq, ctx->d_out + out_elems, out_elems * sizeof(int16_t), hipMemcpyDeviceToHost,

@@ -144,17 +144,17 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3
 
     // staging sources, as in ddc_rx_front
     const uint32_t lane = tid & 63u, wave_base = tid & ~63u;
-    // (kept as 32-bit offsets from the block of the wave's first row: the 64 blocks of a wave lie
-    // within 64 * 768 bytes plus at most one row's padding of each other, which the host bounds)
+    // (kept as 32-bit offsets from the channel row of the wave's first block: the 64 blocks of a
+    // wave lie in that row and the few behind it, which the host bounds; the row pitch may be 0)
     uint32_t src[8];
     const uint8_t *wave_src;
     {
         uint32_t go = g0 + wave_base;
         go = go < total_blocks ? go : total_blocks - 1;
-        const uint32_t ch0 = go / n_blk, b0 = go - ch0 * n_blk;
+        const uint32_t ch0 = go / n_blk;
         {
             // the same value in every lane of the wave: tell the compiler, so that it stays scalar
-            const uint64_t o = (uint64_t)ch0 * row_bytes + (uint64_t)b0 * kBlkBytes;
+            const uint64_t o = (uint64_t)ch0 * row_bytes;
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)o), hi = __builtin_amdgcn_readfirstlane((uint32_t)(o >> 32));
             wave_src = adc + (((uint64_t)hi << 32) | lo);
         }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kMmThreads) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int j = 0; j < 8; j++) {
             const uint32_t row = wave_base + 8u * j + (lane >> 3);
             const uint32_t piece = (lane & 7u) ^ line_swz(row);
-            src[j] = (uint32_t)((size_t)(cho - ch0) * row_bytes + (size_t)bo * kBlkBytes - (size_t)b0 * kBlkBytes) + piece * 16u;
+            src[j] = (uint32_t)((size_t)(cho - ch0) * row_bytes + (size_t)bo * kBlkBytes) + piece * 16u;
             if (go + 8u < total_blocks) {
                 go += 8u;
                 bo += 8u;

@@ -220,15 +220,18 @@ class Ddc:
         self._check(self._L.ddc_rx_get_phase(self._h, channel, C.byref(v)))
         return v.value
 
-    def rx_process(self, packed_rows, samples):
+    def rx_process(self, packed_rows, samples, row_bytes=None):
         """Host path. packed_rows: uint8 [n_channels][row_bytes]; returns spec, voice
-        int16 [n_channels][samples/1024][2]."""
+        int16 [n_channels][samples/1024][2].  row_bytes=0: packed_rows is one row [1][bytes]
+        shared by every channel."""
         a = np.ascontiguousarray(packed_rows, dtype=np.uint8)
-        assert a.ndim == 2 and a.shape[0] == self.n_channels
+        if row_bytes is None:
+            row_bytes = a.shape[1]
+        assert a.ndim == 2 and a.shape[0] == (self.n_channels if row_bytes else 1)
         nf = samples // DECIMATION
         spec = np.zeros((self.n_channels, nf, 2), np.int16)
         voice = np.zeros((self.n_channels, nf, 2), np.int16)
-        self._check(self._L.ddc_rx_process(self._h, _np_ptr(a), a.shape[1], samples, _np_ptr(spec),
+        self._check(self._L.ddc_rx_process(self._h, _np_ptr(a), row_bytes, samples, _np_ptr(spec),
                                            _np_ptr(voice)))
         return spec, voice
 
