@@ -314,9 +314,9 @@ def test_full_size_shard_properties(ddc, orc):
 
 @pytest.mark.parametrize("n_ch,samples,pitch_extra", [(3, 1024 * 40, 0), (200, 1024, 512), (70, 3072, 256)])
 def test_both_ingest_kernels_agree(ddc, orc, monkeypatch, n_ch, samples, pitch_extra):
-    """The library has two forms of the ingest kernel (window moments on the matrix
-    cores, the default, and on the vector ALU, UA3REO_DDC_FRONT=dot2, read when a
-    ctx is created).  Same inputs, two calls each: identical outputs, equal to the
+    """The library has two forms of the ingest kernel (window moments on the vector
+    ALU, the default, and on the matrix cores, UA3REO_DDC_FRONT=mm, read when a ctx
+    is created).  Same inputs, two calls each: identical outputs, equal to the
     oracle, including rail inputs (the one mixer product that wraps) and waves that
     straddle many channels."""
     rng = np.random.default_rng(1234 + n_ch)
@@ -328,8 +328,8 @@ def test_both_ingest_kernels_agree(ddc, orc, monkeypatch, n_ch, samples, pitch_e
     rb = samples // 2 * 3
     res = {}
     for form in ("mm", "dot2"):
-        if form == "dot2":
-            monkeypatch.setenv("UA3REO_DDC_FRONT", "dot2")
+        if form == "mm":
+            monkeypatch.setenv("UA3REO_DDC_FRONT", "mm")
         else:
             monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
         d = ddc.Ddc(n_ch)
@@ -383,11 +383,16 @@ def test_caller_stream_orders_producer_and_consumer(ddc, orc):
     d.close()
 
 
-def test_shared_adc_stream_fans_out_to_all_channels(ddc, orc):
+@pytest.mark.parametrize("form", ["dot2", "mm"])
+def test_shared_adc_stream_fans_out_to_all_channels(ddc, orc, monkeypatch, form):
     """row_bytes = 0: every channel mixes the same ADC row with its own tuning word
     (one converter, many receivers), through both entry points and both ingest kernels'
     addressing (many channels per wave)."""
     torch = pytest.importorskip("torch")
+    if form == "mm":
+        monkeypatch.setenv("UA3REO_DDC_FRONT", "mm")
+    else:
+        monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
     n_ch, samples = 130, 1024 * 6
     rng = np.random.default_rng(91)
     x = rng.integers(-2048, 2048, 2 * samples).astype(np.int16)

@@ -31,7 +31,7 @@ struct ddc_ctx {
     int carry_sel = 0;
     uint2 *d_nco_tab = nullptr;
     uint4 *d_mm_tab = nullptr;         // byte planes of the window weights (B operand of ddc_rx_front_mm)
-    bool front_dot2 = false;           // UA3REO_DDC_FRONT=dot2: the vector-ALU-only ingest kernel instead
+    bool front_mm = false;             // UA3REO_DDC_FRONT=mm: the ingest kernel that reduces on the matrix cores (opt-in)
     // work buffers, sized for cap_blk blocks of 512 samples per channel
     uint32_t cap_blk = 0;
     uint32_t last_blk = 0;
@@ -262,7 +262,7 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         CREATE_TRY(hipMalloc(&ctx->d_mm_tab, mm.size()));
         CREATE_TRY(hipMemcpy(ctx->d_mm_tab, mm.data(), mm.size(), hipMemcpyHostToDevice));
         const char *sel = getenv("UA3REO_DDC_FRONT");
-        ctx->front_dot2 = sel && !strcmp(sel, "dot2");
+        ctx->front_mm = sel && !strcmp(sel, "mm");
     }
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
@@ -478,7 +478,7 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
     // ddc_rx_front_mm addresses the 64 blocks of a wave with 32-bit offsets from the start of the first one's row
     const bool near_rows = (unsigned long long)(64u / n_blk + 2u) * row_bytes + (unsigned long long)n_blk * 768u < (1ull << 32);
-    if (ctx->front_dot2 || !near_rows)
+    if (!ctx->front_mm || !near_rows)
         ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
             adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
     else

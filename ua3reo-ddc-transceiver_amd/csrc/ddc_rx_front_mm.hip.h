@@ -29,6 +29,10 @@
  * matrix instruction; the last five of the block carry zero weight.
  *
  * Output records, carries and every bit of the result are those of ddc_rx_front.
+ *
+ * Opt-in (UA3REO_DDC_FRONT=mm when a ctx is created): the default ingest kernel is
+ * ddc_rx_front, which keeps the whole path on the vector ALU.  This form measures
+ * about 6 % faster; it is kept to document what the matrix cores buy here.
  */
 #pragma once
 #include "ddc_rx_kernels.hip.h"
