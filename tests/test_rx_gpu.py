@@ -266,12 +266,17 @@ def test_many_channels_few_blocks(ddc, orc):
         assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
 
 
-def test_full_size_shard_properties(ddc, orc):
+@pytest.mark.parametrize("form", ["dot2", "mm"])
+def test_full_size_shard_properties(ddc, orc, monkeypatch, form):
     """BASELINE config 5, one GPU's shard (1024 channels x 2^20 samples), checked by
     properties that do not need the oracle at full size: one call equals four
     quarter calls, two channels fed the same row and tuning word agree, and three
-    channels match the oracle on their first 65536 samples."""
+    channels match the oracle on their first 65536 samples.  Both ingest kernels."""
     import torch
+    if form == "mm":
+        monkeypatch.setenv("UA3REO_DDC_FRONT", "mm")
+    else:
+        monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
     n_ch, samples = 1024, 1 << 20
     rb = samples // 2 * 3
     g = torch.Generator(device="cuda").manual_seed(99)
