@@ -317,7 +317,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ddc_rx_front_mm" if os.environ.get("UA3REO_DDC_FRONT") == "mm" else "ddc_rx_front",
+                "kernel": "ddc_rx_front",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -266,17 +266,12 @@ def test_many_channels_few_blocks(ddc, orc):
         assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
 
 
-@pytest.mark.parametrize("form", ["dot2", "mm"])
-def test_full_size_shard_properties(ddc, orc, monkeypatch, form):
+def test_full_size_shard_properties(ddc, orc):
     """BASELINE config 5, one GPU's shard (1024 channels x 2^20 samples), checked by
     properties that do not need the oracle at full size: one call equals four
     quarter calls, two channels fed the same row and tuning word agree, and three
-    channels match the oracle on their first 65536 samples.  Both ingest kernels."""
+    channels match the oracle on their first 65536 samples."""
     import torch
-    if form == "mm":
-        monkeypatch.setenv("UA3REO_DDC_FRONT", "mm")
-    else:
-        monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
     n_ch, samples = 1024, 1 << 20
     rb = samples // 2 * 3
     g = torch.Generator(device="cuda").manual_seed(99)
@@ -318,12 +313,10 @@ def test_full_size_shard_properties(ddc, orc, monkeypatch, form):
 
 
 @pytest.mark.parametrize("n_ch,samples,pitch_extra", [(3, 1024 * 40, 0), (200, 1024, 512), (70, 3072, 256)])
-def test_both_ingest_kernels_agree(ddc, orc, monkeypatch, n_ch, samples, pitch_extra):
-    """The library has two forms of the ingest kernel (window moments on the vector
-    ALU, the default, and on the matrix cores, UA3REO_DDC_FRONT=mm, read when a ctx
-    is created).  Same inputs, two calls each: identical outputs, equal to the
-    oracle, including rail inputs (the one mixer product that wraps) and waves that
-    straddle many channels."""
+def test_rail_inputs_and_padded_rows(ddc, orc, n_ch, samples, pitch_extra):
+    """Rail inputs (the one mixer product that wraps: ADC = -2048 against sin12 = -2048),
+    rows with padding behind them and waves that straddle many channels, two calls
+    each: equal to the oracle."""
     rng = np.random.default_rng(1234 + n_ch)
     adc = rng.integers(-2048, 2048, size=(n_ch, 2 * samples)).astype(np.int16)
     adc[0, 100:700] = -2048
@@ -331,25 +324,20 @@ def test_both_ingest_kernels_agree(ddc, orc, monkeypatch, n_ch, samples, pitch_e
     phis = rng.integers(0, 1 << 22, n_ch).astype(np.uint32)
     phis[0] = 3 << 20  # sin12 = -2048 at every sample
     rb = samples // 2 * 3
-    res = {}
-    for form in ("mm", "dot2"):
-        if form == "mm":
-            monkeypatch.setenv("UA3REO_DDC_FRONT", "mm")
-        else:
-            monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
-        d = ddc.Ddc(n_ch)
-        d.tune_many(phis)
-        outs = []
-        for k in range(2):
-            rows = np.zeros((n_ch, rb + pitch_extra), np.uint8)
-            for c in range(n_ch):
-                rows[c, :rb] = ddc.pack_adc12(adc[c, k * samples:(k + 1) * samples])
-            outs.append(d.rx_process(rows, samples))
-        res[form] = (np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1))
-    assert np.array_equal(res["mm"][0], res["dot2"][0]) and np.array_equal(res["mm"][1], res["dot2"][1])
+    d = ddc.Ddc(n_ch)
+    d.tune_many(phis)
+    outs = []
+    for k in range(2):
+        rows = np.zeros((n_ch, rb + pitch_extra), np.uint8)
+        for c in range(n_ch):
+            rows[c, :rb] = ddc.pack_adc12(adc[c, k * samples:(k + 1) * samples])
+        outs.append(d.rx_process(rows, samples))
+    d.close()
+    spec = np.concatenate([o[0] for o in outs], axis=1)
+    voice = np.concatenate([o[1] for o in outs], axis=1)
     for c in (0, 1, n_ch // 2, n_ch - 1):
         ws, wv = orc.RxChain(int(phis[c])).run(adc[c])
-        assert np.array_equal(res["mm"][0][c], ws) and np.array_equal(res["mm"][1][c], wv), c
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
 
 
 def test_caller_stream_orders_producer_and_consumer(ddc, orc):
@@ -388,16 +376,11 @@ def test_caller_stream_orders_producer_and_consumer(ddc, orc):
     d.close()
 
 
-@pytest.mark.parametrize("form", ["dot2", "mm"])
-def test_shared_adc_stream_fans_out_to_all_channels(ddc, orc, monkeypatch, form):
+def test_shared_adc_stream_fans_out_to_all_channels(ddc, orc):
     """row_bytes = 0: every channel mixes the same ADC row with its own tuning word
-    (one converter, many receivers), through both entry points and both ingest kernels'
-    addressing (many channels per wave)."""
+    (one converter, many receivers), through both entry points (many channels per
+    wave)."""
     torch = pytest.importorskip("torch")
-    if form == "mm":
-        monkeypatch.setenv("UA3REO_DDC_FRONT", "mm")
-    else:
-        monkeypatch.delenv("UA3REO_DDC_FRONT", raising=False)
     n_ch, samples = 130, 1024 * 6
     rng = np.random.default_rng(91)
     x = rng.integers(-2048, 2048, 2 * samples).astype(np.int16)

@@ -15,7 +15,6 @@
 
 #include "../../include/ua3reo_ddc.h"
 #include "ddc_rx_kernels.hip.h"
-#include "ddc_rx_front_mm.hip.h"
 #include "ddc_tx_kernels.hip.h"
 #include "ddc_audio_kernels.hip.h"
 
@@ -30,11 +29,10 @@ struct ddc_ctx {
     uint32_t *d_carry[2] = {nullptr, nullptr};
     int carry_sel = 0;
     uint2 *d_nco_tab = nullptr;
-    uint4 *d_mm_tab = nullptr;         // byte planes of the window weights (B operand of ddc_rx_front_mm)
-    bool front_mm = false;             // UA3REO_DDC_FRONT=mm: the ingest kernel that reduces on the matrix cores (opt-in)
     // work buffers, sized for cap_blk blocks of 512 samples per channel
     uint32_t cap_blk = 0;
     uint32_t last_blk = 0;
+    const int16_t *last_cic = nullptr; // rx_cic outputs of the last RX call (work buffer or static area)
     unsigned long long *d_mom = nullptr;
     int16_t *d_cic = nullptr;
     int16_t *d_comp = nullptr;
@@ -253,17 +251,6 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         return bail(-EFAULT);
     }
     CREATE_TRY(hipMemcpyAsync(ctx->d_nco_tab, tab.data(), 2048 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    {
-        std::vector<uint8_t> mm(ddc::kMmTabRows * 256);
-        if (!ddc::build_mm_table(mm.data())) {
-            ctx->err = "a window weight does not fit its byte planes";
-            return bail(-EFAULT);
-        }
-        CREATE_TRY(hipMalloc(&ctx->d_mm_tab, mm.size()));
-        CREATE_TRY(hipMemcpy(ctx->d_mm_tab, mm.data(), mm.size(), hipMemcpyHostToDevice));
-        const char *sel = getenv("UA3REO_DDC_FRONT");
-        ctx->front_mm = sel && !strcmp(sel, "mm");
-    }
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
@@ -332,7 +319,7 @@ void ddc_destroy(ddc_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mm_tab, ctx->d_mom,
+    void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
                      ctx->d_out, ctx->d_tx_xs, ctx->d_fft_rows, ctx->d_wtf, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
                      ctx->d_stage[2] };
@@ -444,11 +431,10 @@ int ddc_rx_get_phase(ddc_ctx *ctx, int32_t channel, uint32_t *phase22)
     return 0;
 }
 
-int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
-                       int16_t *spec_iq, int16_t *voice_iq)
+// Argument checks shared by the RX entry points; fills the block counts.
+static int rx_check_args(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples, const int16_t *spec_iq,
+                         const int16_t *voice_iq, uint32_t *n_blk_out)
 {
-    if (!ctx) return -EINVAL;
-    if (samples == 0) return 0;
     if (!adc12 || !spec_iq || !voice_iq) return fail(ctx, -EINVAL, "null buffer");
     if (samples % DDC_DECIMATION) return fail(ctx, -EINVAL, "samples must be a multiple of 1024");
     if (row_bytes % 16 || ((uintptr_t)adc12 % 16)) return fail(ctx, -EINVAL, "ADC rows must be 16-byte aligned");
@@ -457,12 +443,60 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     const uint64_t n_blk64 = samples / 512;
     const uint64_t total64 = n_blk64 * ctx->cfg.n_channels;
     if (total64 >= (1ull << 31)) return fail(ctx, -EINVAL, "more than 2^31 blocks of 512 samples in one call");
-    const uint32_t n_blk = (uint32_t)n_blk64, total = (uint32_t)total64, nch = ctx->cfg.n_channels;
-    const uint32_t nf = n_blk / 2;
-    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    int rc = ensure_capacity(ctx, n_blk);
-    if (rc) return rc;
+    if (ctx->adc_stats && ctx->cfg.n_channels > 65535u)
+        return fail(ctx, -EINVAL, "ADC statistics are limited to 65535 channels per ctx");
+    *n_blk_out = (uint32_t)n_blk64;
+    return 0;
+}
+
+// Queues one RX call on the ctx stream with the given work buffers.  pev: three
+// events to record around the ingest kernel and the rest, or null.
+static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples, uint32_t n_blk,
+                     int16_t *spec_iq, int16_t *voice_iq, unsigned long long *mom, int16_t *cic, int16_t *comp,
+                     hipEvent_t *pev)
+{
+    const uint32_t nch = ctx->cfg.n_channels, total = n_blk * nch, nf = n_blk / 2;
     hipStream_t st = ctx->stream;
+    ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, mom, cic, comp,
+                                                 n_blk);
+    const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
+    uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
+    if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
+    ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
+        adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, mom, ctx->d_nco_tab);
+    if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
+    const uint32_t ctiles = (n_blk + 255) / 256;
+    ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(mom, n_blk, ctiles, cic);
+    const uint32_t nfr = nch * nf;
+    ddc::ddc_rx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(cic, n_blk, nch, comp, spec_iq);
+    const uint32_t tiles = (nf + 255) / 256;
+    ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(comp, nf, tiles, voice_iq);
+    ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, mom, cic, comp,
+                                                 ctx->d_acc, ctx->d_phi, n_blk, (uint32_t)samples);
+    if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
+    if (ctx->adc_stats) {
+        const uint32_t pieces = (uint32_t)(samples / 32);
+        const uint32_t gx = std::min<uint32_t>((pieces + 255) / 256, std::max<uint32_t>(1, 4096 / nch));
+        ddc::ddc_adc_minmax<<<dim3(gx, nch), 256, 0, st>>>(adc12, row_bytes, pieces, ctx->d_adc_min, ctx->d_adc_max);
+    }
+    const hipError_t e = hipGetLastError();
+    // the ingest kernel is queued: the saved carries now belong to the other buffer whatever follows
+    ctx->carry_sel ^= 1;
+    if (e != hipSuccess) return fail(ctx, -EIO, std::string("RX launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                       int16_t *spec_iq, int16_t *voice_iq)
+{
+    if (!ctx) return -EINVAL;
+    if (samples == 0) return 0;
+    uint32_t n_blk = 0;
+    int rc = rx_check_args(ctx, adc12, row_bytes, samples, spec_iq, voice_iq, &n_blk);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    rc = ensure_capacity(ctx, n_blk);
+    if (rc) return rc;
     hipEvent_t *pev = nullptr;
     if (ctx->profile) {
         pev = ctx->ev[ctx->prof_head];
@@ -471,39 +505,10 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
         ctx->prof_head = (ctx->prof_head + 1) % ddc_ctx::kProfRing;
         if (ctx->prof_count < ddc_ctx::kProfRing) ctx->prof_count++;
     }
-    ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp,
-                                                 ctx->d_mom, ctx->d_cic, ctx->d_comp, n_blk);
-    const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
-    uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
-    if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
-    // ddc_rx_front_mm addresses the 64 blocks of a wave with 32-bit offsets from the start of the first one's row
-    const bool near_rows = (unsigned long long)(64u / n_blk + 2u) * row_bytes + (unsigned long long)n_blk * 768u < (1ull << 32);
-    if (!ctx->front_mm || !near_rows)
-        ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
-            adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab);
-    else
-        ddc::ddc_rx_front_mm<<<(total + ddc::kMmThreads - 1) / ddc::kMmThreads, ddc::kMmThreads, 0, st>>>(
-            adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, ctx->d_mom, ctx->d_nco_tab,
-            ctx->d_mm_tab);
-    ctx->carry_sel ^= 1;
-    if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
-    const uint32_t ctiles = (n_blk + 255) / 256;
-    ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(ctx->d_mom, n_blk, ctiles, ctx->d_cic);
-    const uint32_t nfr = nch * nf;
-    ddc::ddc_rx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(ctx->d_cic, n_blk, nch, ctx->d_comp, spec_iq);
-    const uint32_t tiles = (nf + 255) / 256;
-    ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(ctx->d_comp, nf, tiles, voice_iq);
-    ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_mom,
-                                                 ctx->d_cic, ctx->d_comp, ctx->d_acc, ctx->d_phi, n_blk,
-                                                 (uint32_t)samples);
-    if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
-    if (ctx->adc_stats) {
-        const uint32_t pieces = (uint32_t)(samples / 32);
-        const uint32_t gx = std::min<uint32_t>((pieces + 255) / 256, std::max<uint32_t>(1, 4096 / nch));
-        ddc::ddc_adc_minmax<<<dim3(gx, nch), 256, 0, st>>>(adc12, row_bytes, pieces, ctx->d_adc_min, ctx->d_adc_max);
-    }
-    HIP_TRY(ctx, hipGetLastError());
+    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq, ctx->d_mom, ctx->d_cic, ctx->d_comp, pev);
+    if (rc) return rc;
     ctx->last_blk = n_blk;
+    ctx->last_cic = ctx->d_cic;
     return 0;
 }
 
@@ -551,7 +556,7 @@ int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples)
     const uint32_t n_blk = (uint32_t)(samples / 512);
     if (n_blk == 0 || n_blk != ctx->last_blk) return fail(ctx, -EINVAL, "ddc_rx_read_cic: size differs from the last call");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    HIP_TRY(ctx, hipMemcpy2DAsync(cic_iq, (size_t)n_blk * 4, ctx->d_cic + (size_t)ddc::kCicHist * 2,
+    HIP_TRY(ctx, hipMemcpy2DAsync(cic_iq, (size_t)n_blk * 4, ctx->last_cic + (size_t)ddc::kCicHist * 2,
                                   (size_t)(ddc::kCicHist + n_blk) * 4, (size_t)n_blk * 4, ctx->cfg.n_channels,
                                   hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
