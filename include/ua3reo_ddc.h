@@ -83,6 +83,25 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
                        int16_t *spec_iq, int16_t *voice_iq);
 int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
                    int16_t *spec_iq, int16_t *voice_iq);
+/* ddc_rx_process_dev for callers that must not allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc): same
+ * arguments, same results, same carried state, but the work buffers of the call
+ * (window moments, rx_cic and compensator outputs) live in one fixed work area
+ * of ddc_rx_static_scratch_bytes() = 32 MiB per GPU inside the library instead
+ * of buffers that grow with the largest call.  No counterpart in the reference.
+ * The call allocates and frees nothing and records no timing events.
+ * -E2BIG (with the byte counts in ddc_last_error) when n_channels x samples needs
+ * more than the area holds: ddc_rx_static_scratch_need() tells beforehand
+ * (86 bytes per channel per 512 samples plus 1680 bytes per channel, each of the
+ * three buffers rounded up to 256 bytes).
+ * Every ctx on a GPU shares that GPU's area: calls of this entry point that
+ * overlap in time on one GPU (two ctxs on two streams) race; calls on one stream,
+ * or ordered by the caller, do not.  Mixing it with ddc_rx_process_dev on the
+ * same ctx is fine: the carried state lives in the ctx, not in the area. */
+int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                              int16_t *spec_iq, int16_t *voice_iq);
+size_t ddc_rx_static_scratch_bytes(void);
+size_t ddc_rx_static_scratch_need(uint32_t n_channels, size_t samples);
 /* Debug tap: the raw rx_cic outputs of the last ddc_rx_process* call,
  * [channel][samples/512][2] int16 (host pointer). */
 int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples);

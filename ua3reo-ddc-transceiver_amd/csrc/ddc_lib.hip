@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,7 @@ struct ddc_ctx {
     uint32_t cap_blk = 0;
     uint32_t last_blk = 0;
     const int16_t *last_cic = nullptr; // rx_cic outputs of the last RX call (work buffer or static area)
+    unsigned char *scratch_base = nullptr; // this device's copy of the static work area
     unsigned long long *d_mom = nullptr;
     int16_t *d_cic = nullptr;
     int16_t *d_comp = nullptr;
@@ -169,6 +171,49 @@ const double kZoomFir[4][4] = {
 
 } // namespace
 
+// Work area of ddc_rx_process_dev_static: the window moments, rx_cic outputs and
+// compensator outputs of one call (what ensure_capacity allocates for the other
+// entry points).  One copy per GPU the library runs on, held until the process
+// ends.  On the host this name is only a handle for hipGetSymbolAddress: the
+// device address it yields (per device, kept in g_scratch_ptr) is what kernels,
+// memsets and copies are given.
+#define DDC_STATIC_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) unsigned char scratch[DDC_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// Address of this device's copy of the work area; `device` must be current.
+int scratch_address(ddc_ctx *ctx, int device, unsigned char **out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(ctx, -EINVAL, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p || ((uintptr_t)p % 256)) return fail(ctx, -EFAULT, "static work area has no usable device address");
+        g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
+// Byte offsets of the three work buffers inside one area, each 256-byte aligned.
+struct WorkLayout { size_t mom, cic, comp, total; };
+WorkLayout work_layout(size_t nch, size_t n_blk)
+{
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    WorkLayout w;
+    w.mom = 0;
+    w.cic = up(nch * (ddc::kMomHist + n_blk) * 10 * sizeof(unsigned long long));
+    w.comp = w.cic + up(nch * (ddc::kCicHist + n_blk) * 2 * sizeof(int16_t));
+    w.total = w.comp + up(nch * (ddc::kCompHist + n_blk / 2) * 2 * sizeof(int16_t));
+    return w;
+}
+} // namespace
+
 namespace ddc {
 // history <-> work buffer moves: the work buffers are laid out for the block
 // count of the current call, the saved history is not.
@@ -229,6 +274,7 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
+    if (scratch_address(ctx, cfg->device, &ctx->scratch_base) != 0) return bail(-EIO);
     const size_t nch = cfg->n_channels;
     CREATE_TRY(hipMalloc(&ctx->d_acc, nch * 4));
     CREATE_TRY(hipMalloc(&ctx->d_phi, nch * 4));
@@ -509,6 +555,40 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     if (rc) return rc;
     ctx->last_blk = n_blk;
     ctx->last_cic = ctx->d_cic;
+    return 0;
+}
+
+size_t ddc_rx_static_scratch_bytes(void) { return DDC_STATIC_SCRATCH_BYTES; }
+
+size_t ddc_rx_static_scratch_need(uint32_t n_channels, size_t samples)
+{
+    return work_layout(n_channels, samples / 512).total;
+}
+
+int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
+                              int16_t *spec_iq, int16_t *voice_iq)
+{
+    if (!ctx) return -EINVAL;
+    if (samples == 0) return 0;
+    uint32_t n_blk = 0;
+    int rc = rx_check_args(ctx, adc12, row_bytes, samples, spec_iq, voice_iq, &n_blk);
+    if (rc) return rc;
+    const WorkLayout w = work_layout(ctx->cfg.n_channels, n_blk);
+    if (w.total > DDC_STATIC_SCRATCH_BYTES) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "ddc_rx_process_dev_static: %u channels x %zu samples need %zu bytes of work area, "
+                 "the static one holds %u", ctx->cfg.n_channels, samples, w.total, DDC_STATIC_SCRATCH_BYTES);
+        return fail(ctx, -E2BIG, msg);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    unsigned char *base = ctx->scratch_base; // resolved by ddc_create on this ctx's device
+    if (!base) return fail(ctx, -EFAULT, "static work area was not resolved when the ctx was created");
+    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq,
+                   reinterpret_cast<unsigned long long *>(base + w.mom), reinterpret_cast<int16_t *>(base + w.cic),
+                   reinterpret_cast<int16_t *>(base + w.comp), nullptr);
+    if (rc) return rc;
+    ctx->last_blk = n_blk;
+    ctx->last_cic = reinterpret_cast<int16_t *>(base + w.cic);
     return 0;
 }
 

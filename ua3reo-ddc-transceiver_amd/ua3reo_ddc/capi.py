@@ -74,6 +74,11 @@ def lib():
     L.ddc_rx_set_phase.argtypes = [vp, i32, u32]
     L.ddc_rx_get_phase.argtypes = [vp, i32, C.POINTER(u32)]
     L.ddc_rx_process_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.ddc_rx_process_dev_static.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.ddc_rx_static_scratch_bytes.argtypes = []
+    L.ddc_rx_static_scratch_bytes.restype = sz
+    L.ddc_rx_static_scratch_need.argtypes = [u32, sz]
+    L.ddc_rx_static_scratch_need.restype = sz
     L.ddc_rx_process.argtypes = [vp, vp, sz, sz, vp, vp]
     L.ddc_rx_read_cic.argtypes = [vp, vp, sz]
     L.ddc_tx_process_dev.argtypes = [vp, vp, sz, vp]
@@ -238,6 +243,11 @@ class Ddc:
     def rx_process_dev(self, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr):
         """Device path: raw device addresses (ints), asynchronous on the ctx stream."""
         self._check(self._L.ddc_rx_process_dev(self._h, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr))
+
+    def rx_process_dev_static(self, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr):
+        """ddc_rx_process_dev with the call's work buffers in the library's fixed
+        per-GPU work area: allocates nothing; DdcError (-E2BIG) beyond its size."""
+        self._check(self._L.ddc_rx_process_dev_static(self._h, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr))
 
     def rx_read_cic(self, samples):
         out = np.zeros((self.n_channels, samples // 512, 2), np.int16)
