@@ -292,6 +292,19 @@ int ddc_autogain_step(ddc_autogain *st, int16_t adc_max_amplitude);
 /* S-meter extremes, AGC / ALC gain, CW decoder text (waits for the ctx stream). */
 int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
 
+/* Read-out of a constant table as compiled into this library (host memory, no GPU
+ * needed), so that a test can compare what ships with the reference's numbers:
+ * "rx_ciccomp_h" int16[65] (FPGA/rx_ciccomp.vhd:81-146 interleaved), "rx_hilb_c"
+ * int16[256] (rx_hilb.vhd:77-332), "tx_ciccomp_p1" / "tx_ciccomp_p2" int16[24]
+ * (tx_ciccomp.vhd:81-128), "tx_hilbert_i" / "tx_hilbert_q" float[201], "hpf_k"
+ * float[6][6], "hpf_v" float[6][7], "lpf_k" float[32][11], "lpf_v" float[32][12],
+ * "lpf_stages" / "hpf_hz" / "lpf_hz" int[], "sql_hpf_k" float[6], "sql_hpf_v" float[7]
+ * (STM32/Src/audio_filters.c:41-126), "zoom_biquad" double[4][20], "zoom_fir"
+ * double[4][4] (fft.c:72-183), "nco_coarse" uint32[2048][2] ({2 sc | 2 cc << 16,
+ * 2 cc | -2 sc << 16} of the coarse ROMs), "nco_fine_sine" int16[2048] (the kernels'
+ * arithmetic form of the fine sine ROM).  out = NULL only reports the size. */
+int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes);
+
 /* Packed-ADC helpers and the synthetic test signal of the benchmark
  * (two tones + uniform noise, xorshift64* seeded 0x5EED0000 + channel). */
 void ddc_pack_adc12(const int16_t *samples, size_t n, uint8_t *packed);

@@ -18,7 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../ua3reo-ddc-transceiver_amd/csrc/ddc_audio_coeffs.h"
+#define ORACLE_AUDIO_TABLES
+#include "oracle_tables.h"
 
 #define BLOCK 192          /* FPGA_AUDIO_BUFFER_HALF_SIZE, audio_processor.h:10-11 */
 #define SUB 64             /* APROCESSOR_BLOCK_SIZE, audio_processor.h:12 */
@@ -171,30 +172,8 @@ static void notch_coeffs(uint32_t fc, float c[5])
     c[0] = a0; c[1] = a1; c[2] = a2; c[3] = -b1; c[4] = -b2;
 }
 
-/* Zoom-FFT coefficient sets, fft.c:76-186 (literals are double in the firmware and
- * narrow to float32 when stored) */
-static const double zoom_biquad[4][20] = {
-    { 0.228454526413293696,0.077639329099949764,0.228454526413293696,0.635534925142242080,-0.170083307068779194,
-      0.436788292542003964,0.232307972937606161,0.436788292542003964,0.365885230717786780,-0.471769788739400842,
-      0.535974654742658707,0.557035600464780845,0.535974654742658707,0.125740787233286133,-0.754725697183384336,
-      0.501116342273565607,0.914877831284765408,0.501116342273565607,0.013862536615004284,-0.930973052446900984 },
-    { 0.182208761527446556,-0.222492493114674145,0.182208761527446556,1.326111070880959810,-0.468036100821178802,
-      0.337123762652097259,-0.366352718812586853,0.337123762652097259,1.337053579516321200,-0.644948386007929031,
-      0.336163175380826074,-0.199246162162897811,0.336163175380826074,1.354952684569386670,-0.828032873168141115,
-      0.178588201750411041,0.207271695028067304,0.178588201750411041,1.386486967455699220,-0.950935065984588657 },
-    { 0.185643392652478922,-0.332064345389014803,0.185643392652478922,1.654637402827731090,-0.693859842743674182,
-      0.327519300813245984,-0.571358085216950418,0.327519300813245984,1.715375037176782860,-0.799055553586324407,
-      0.283656142708241688,-0.441088976843048652,0.283656142708241688,1.778230635987093860,-0.904453944560528522,
-      0.079685368654848945,-0.011231810140649204,0.079685368654848945,1.825046003243238070,-0.973184930412286708 },
-    { 0.194769868656866380,-0.379098413160710079,0.194769868656866380,1.824436402073870810,-0.834877726226893380,
-      0.333973874901496770,-0.646106479315673776,0.333973874901496770,1.871892825636887640,-0.893734096124207178,
-      0.272903880596429671,-0.513507745397738469,0.272903880596429671,1.918161772571113750,-0.950461788366234739,
-      0.053535383722369843,-0.069683422367188122,0.053535383722369843,1.948900719896301760,-0.986288064973853129 } };
-static const double zoom_fir_taps[4][4] = {
-    { 475.1179397144384210E-6, 0.503905202786044337, 0.503905202786044337, 475.1179397144384210E-6 },
-    { 0.198273254218889416, 0.298085149879260325, 0.298085149879260325, 0.198273254218889416 },
-    { 0.199820836596682871, 0.272777397353925699, 0.272777397353925699, 0.199820836596682871 },
-    { 0.199820836596682871, 0.272777397353925699, 0.272777397353925699, 0.199820836596682871 } };
+/* Zoom-FFT coefficient sets (fft.c:76-186; double literals in the firmware, narrowed to
+ * float32 when stored): zoom_biquad / zoom_fir_taps in oracle_tables.h */
 
 /* initAudioProcessor + ReinitAudioFilters + InitNotchFilter + InitAGC +
  * InitNoiseReduction + CWDecoder_Init + FFT state, all from power-on zeros */

@@ -14,7 +14,8 @@ _SO = os.path.join(_HERE, "libddc_oracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("ddc_oracle.c", "audio_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ddc_oracle.c", "audio_oracle.c", "oracle_tables.h", "oracle_cic_consts.h",
+                                          "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
     return _SO

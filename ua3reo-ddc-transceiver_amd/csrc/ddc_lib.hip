@@ -1392,6 +1392,53 @@ int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
     return ddc_tune(ctx, channel, phi);
 }
 
+/* ---- the constant tables compiled into this library ---------------------- */
+
+int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
+{
+    if (!name || !bytes) return -EINVAL;
+    std::vector<uint2> nco;
+    std::vector<int16_t> fine;
+    const void *src = nullptr;
+    size_t n = 0;
+    const std::string k(name);
+#define TAB(key, obj) if (k == key) { src = obj; n = sizeof obj; }
+    TAB("rx_ciccomp_h", rx_ciccomp_h)
+    TAB("rx_hilb_c", rx_hilb_c)
+    TAB("tx_ciccomp_p1", tx_ciccomp_p1)
+    TAB("tx_ciccomp_p2", tx_ciccomp_p2)
+    TAB("tx_hilbert_i", tx_hilbert_i)
+    TAB("tx_hilbert_q", tx_hilbert_q)
+    TAB("hpf_hz", ddc_hpf_hz)
+    TAB("lpf_hz", ddc_lpf_hz)
+    TAB("lpf_stages", ddc_lpf_stages)
+    TAB("hpf_k", ddc_hpf_k)
+    TAB("hpf_v", ddc_hpf_v)
+    TAB("lpf_k", ddc_lpf_k)
+    TAB("lpf_v", ddc_lpf_v)
+    TAB("sql_hpf_k", ddc_sql_hpf_k)
+    TAB("sql_hpf_v", ddc_sql_hpf_v)
+    TAB("zoom_biquad", kZoomBiquad)
+    TAB("zoom_fir", kZoomFir)
+#undef TAB
+    if (k == "nco_coarse") {          // as uploaded for the kernels: {2 sc | 2 cc << 16, 2 cc | -2 sc << 16}
+        if (build_nco_table(nco) != 0) return fail(nullptr, -EFAULT, "fine-sine shortcut does not reproduce the NCO fine ROM");
+        src = nco.data();
+        n = nco.size() * sizeof(uint2);
+    } else if (k == "nco_fine_sine") { // the kernels' arithmetic fine sine for every 11-bit fine phase
+        fine.resize(2048);
+        for (uint32_t f = 0; f < 2048; f++) fine[f] = (int16_t)((32u * f * DDC_SF16_K + DDC_SF16_R) >> 24);
+        src = fine.data();
+        n = fine.size() * sizeof(int16_t);
+    }
+    if (!src) return fail(nullptr, -ENOENT, "no such table: " + k);
+    *bytes = n;
+    if (!out) return 0;
+    if (cap < n) return fail(nullptr, -ENOSPC, "buffer too small for table " + k);
+    memcpy(out, src, n);
+    return 0;
+}
+
 /* ---- packed ADC words and the synthetic bench signal ------------------- */
 
 void ddc_pack_adc12(const int16_t *samples, size_t n, uint8_t *packed)

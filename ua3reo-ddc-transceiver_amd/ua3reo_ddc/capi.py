@@ -99,6 +99,7 @@ def lib():
     L.ddc_parse_params.restype = None
     L.ddc_set_params.argtypes = [vp, i32, vp]
     L.ddc_pack_adc12.argtypes = [vp, sz, vp]
+    L.ddc_debug_table.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
     L.ddc_pack_adc12.restype = None
     L.ddc_unpack_adc12.argtypes = [vp, sz, vp]
     L.ddc_unpack_adc12.restype = None
@@ -165,6 +166,20 @@ def audio_params(mode="USB", agc=1, dnr=0, notch=0, mute=0, cw_decoder=0, fm_sql
     m = MODES[mode] if isinstance(mode, str) else int(mode)
     return AudioParams(m, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume, iq_swap, fft_averaging,
                        fft_zoom, rf_power, tune, key, 0, 0, filter_width, hpf_pass, notch_fc, agc_speed, rf_gain)
+
+
+def debug_table(name, dtype):
+    """A constant table as compiled into the library (ddc_debug_table), as a flat numpy array."""
+    L = lib()
+    n = C.c_size_t(0)
+    rc = L.ddc_debug_table(name.encode(), None, 0, C.byref(n))
+    if rc != 0:
+        raise DdcError("error %d: %s" % (rc, L.ddc_last_error(None).decode()))
+    out = np.zeros(n.value // np.dtype(dtype).itemsize, dtype)
+    rc = L.ddc_debug_table(name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(n))
+    if rc != 0:
+        raise DdcError("error %d: %s" % (rc, L.ddc_last_error(None).decode()))
+    return out
 
 
 def _np_ptr(a):
