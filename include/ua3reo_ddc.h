@@ -213,6 +213,15 @@ typedef struct ddc_audio_status {
     char cw_text[16];             /* CW_Decoder_Text: last 15 decoded characters */
 } ddc_audio_status;
 
+/* TRX_setMode (STM32/Src/trx_manager.c:193-220): the mode -> Filter_Width policy of
+ * the transceiver.  Sets p->mode and p->filter_width from the three widths the
+ * operator keeps (TRX.SSB_Filter for LSB / USB / DIGI_L / DIGI_U / AM, TRX.CW_Filter
+ * for CW_L / CW_U, TRX.FM_Filter for NFM, 0 for WFM; IQ, NO_TX and LOOPBACK leave the
+ * width as it is) and touches no other field; follow it with ddc_audio_configure,
+ * as the firmware follows it with ReinitAudioFilters.  -EINVAL for a mode > 11. */
+int ddc_audio_params_for_mode(uint8_t mode, uint16_t ssb_filter, uint16_t cw_filter, uint16_t fm_filter,
+                              ddc_audio_params *p);
+
 /* initAudioProcessor + ReinitAudioFilters + InitNotchFilter + InitAGC +
  * InitNoiseReduction + CWDecoder_Init for `channel` (-1 = all): filter selection
  * (audio_filters.c:141-339), notch design (calcBiquad :375-494), state zeroed.
@@ -243,6 +252,15 @@ int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t
                              int32_t *audio_lr);
 int ddc_audio_rx_process(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames,
                          int32_t *audio_lr);
+/* The USB-audio frames of the RX path (audio_processor.c:415-432, USB_AUDIO_rx_buffer_a/b):
+ * one int16 per int32 entry of audio_lr, (int16_t)((int32_t)v * (1.0f / volume * 100.0f)),
+ * i.e. the codec samples with the volume setting taken out again; the cast is the
+ * Cortex-M4F's (towards zero and saturating in 32 bits, then the low 16 bits; volume 0
+ * gives an infinite factor: 0 stays 0, other samples become -1 / 0).  audio_lr as
+ * ddc_audio_rx_process* writes it, [n_channels][n_frames][2]; usb_lr the same shape in
+ * int16; n_frames even.  Uses the volume of the channel's current audio parameters. */
+int ddc_audio_usb_frames_dev(ddc_ctx *ctx, const int32_t *audio_lr, size_t n_frames, int16_t *usb_lr);
+int ddc_audio_usb_frames(ddc_ctx *ctx, const int32_t *audio_lr, size_t n_frames, int16_t *usb_lr);
 /* FFT_doFFT (fft.c:212-331, zoom 1) + the colour row of FFT_printFFT (:361-379,
  * :506-539) over consecutive 512-sample frames of SPEC.  n_frames a multiple of
  * 512; bins: [n_channels][n_frames/512][256] float (FFTOutput_mean after each

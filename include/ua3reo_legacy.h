@@ -80,6 +80,7 @@ extern struct TRX_SETTINGS {
     uint16_t SSB_HPF_pass;
     bool AutoGain; /* settings.h:90 */
     bool ATT, LPF, BPF;
+    uint16_t CW_Filter, SSB_Filter, FM_Filter; /* settings.h:82-84: the widths TRX_setMode hands to the VFO */
 } TRX;
 
 /* trx_manager.h: transceiver state the path reads */
@@ -88,6 +89,7 @@ extern volatile bool TRX_ADC_OTR, TRX_DAC_OTR;
 extern volatile int16_t TRX_ADC_MINAMPLITUDE, TRX_ADC_MAXAMPLITUDE;
 VFO *CurrentVFO(void);    /* settings.c */
 uint8_t TRX_getMode(void); /* trx_manager.c */
+void TRX_setMode(uint8_t _mode); /* trx_manager.c:193-220: mode -> Filter_Width, then ReinitAudioFilters */
 void TRX_DoAutoGain(void);  /* trx_manager.c:268: once a second, on TRX_ADC_MAXAMPLITUDE; sets TRX.Preamp / TRX.ATT */
 bool TRX_on_TX(void);      /* trx_manager.c:  ptt | tune | CAT ptt | key */
 
@@ -114,6 +116,14 @@ extern volatile bool Processor_NeedRXBuffer, Processor_NeedTXBuffer;
 extern volatile float32_t Processor_TX_MAX_amplitude, ALC_need_gain;
 extern volatile float32_t Processor_RX_Audio_Samples_MAX_value, Processor_RX_Audio_Samples_MIN_value;
 extern float32_t FPGA_Audio_Buffer_Q_tmp[FPGA_AUDIO_BUFFER_HALF_SIZE], FPGA_Audio_Buffer_I_tmp[FPGA_AUDIO_BUFFER_HALF_SIZE];
+
+/* usbd_audio_if.h:14-18, usbd_ua3reo.h:70: the USB-audio side of processRxAudio
+ * (audio_processor.c:415-432).  While USB_AUDIO_need_rx_buffer is set, processRxAudio
+ * fills buffer a (USB_AUDIO_current_rx_buffer false) or b with the int16 frames of the
+ * block and clears the flag. */
+#define USB_AUDIO_RX_BUFFER_SIZE (FPGA_AUDIO_BUFFER_SIZE * 2)
+extern int16_t USB_AUDIO_rx_buffer_a[USB_AUDIO_RX_BUFFER_SIZE / 2], USB_AUDIO_rx_buffer_b[USB_AUDIO_RX_BUFFER_SIZE / 2];
+extern volatile bool USB_AUDIO_current_rx_buffer, USB_AUDIO_need_rx_buffer;
 
 /* fft.h:25-35.  FFT_doFFT leaves the smoothed bins in FFTOutput_mean and the
  * newest waterfall row (RGB565, fft-shifted) in FFT_waterfall_row, where the

@@ -495,6 +495,23 @@ void orc_audio_rx_run(orc_audio_t *s, const int16_t *spec_iq, const int16_t *voi
         orc_audio_rx_block(s, spec_iq + 2 * b, voice_iq + 2 * b, out + 2 * b);
 }
 
+/* USB-audio frames (audio_processor.c:415-432): (int16_t)((int32_t)v * (1.0f / Volume * 100.0f)),
+ * the cast as the Cortex-M4F performs it (vcvt.s32.f32: towards zero, saturating, NaN -> 0; then
+ * the low 16 bits). */
+void orc_audio_usb_frames(const int32_t *in, size_t n, uint8_t volume, int16_t *out)
+{
+    const float gain = (1.0f / (float)volume) * 100.0f;
+    for (size_t i = 0; i < n; i++) {
+        const float f = (float)in[i] * gain;
+        int32_t v;
+        if (f != f) v = 0;
+        else if (f >= 2147483648.0f) v = 2147483647;
+        else if (f <= -2147483648.0f) v = (-2147483647 - 1);
+        else v = (int32_t)f;
+        out[i] = (int16_t)(uint16_t)((uint32_t)v & 0xFFFFu);
+    }
+}
+
 void orc_audio_status(const orc_audio_t *s, float *smeter_max, float *smeter_min, float *agc_gain,
                       char text[16], uint16_t *wpm, int *squelched)
 {

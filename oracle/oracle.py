@@ -411,6 +411,27 @@ class Audio:
         return bins, row, hts
 
 
+def usb_frames(audio_lr, volume):
+    """audio_processor.c:415-432 on an int32 array of any shape -> int16 of the same shape."""
+    a = np.ascontiguousarray(audio_lr, dtype=np.int32)
+    out = np.zeros(a.shape, np.int16)
+    lib().orc_audio_usb_frames(_p(a), C.c_size_t(a.size), C.c_uint8(volume), _p(out))
+    return out
+
+
+def params_for_mode(mode, ssb_filter, cw_filter, fm_filter, filter_width):
+    """TRX_setMode (trx_manager.c:193-220): the Filter_Width the mode selects."""
+    if mode in (0, 1, 5, 6, 10):
+        return ssb_filter
+    if mode in (3, 4):
+        return cw_filter
+    if mode == 8:
+        return fm_filter
+    if mode == 9:
+        return 0
+    return filter_width
+
+
 def autogain_step(state, adc_max):
     """TRX_DoAutoGain (trx_manager.c:268-356) on state = [stage, wait, preamp, att] (list of 4 ints, updated in place)."""
     st = (C.c_uint8 * 4)(*state)

@@ -16,7 +16,7 @@ class TrxSettings(C.Structure):
                 ("FFT_Zoom", C.c_uint8), ("NotchFilter", C.c_bool), ("NotchFC", C.c_uint16), ("CWDecoder", C.c_bool),
                 ("FFT_Enabled", C.c_bool), ("CW_GENERATOR_SHIFT_HZ", C.c_uint16), ("FFT_Averaging", C.c_uint8),
                 ("SSB_HPF_pass", C.c_uint16), ("AutoGain", C.c_bool), ("ATT", C.c_bool), ("LPF", C.c_bool),
-                ("BPF", C.c_bool)]
+                ("BPF", C.c_bool), ("CW_Filter", C.c_uint16), ("SSB_Filter", C.c_uint16), ("FM_Filter", C.c_uint16)]
 
 
 class Legacy:
@@ -33,9 +33,10 @@ class Legacy:
         L.DoAGC.argtypes = [C.c_void_p, C.c_int16]
         L.processNoiseReduction.argtypes = [C.c_void_p, C.c_void_p]
         L.CWDecoder_Process.argtypes = [C.c_void_p]
+        L.TRX_setMode.argtypes = [C.c_uint8]
         for f in ("FPGA_Init", "FPGA_fpgadata_iqclock", "FPGA_fpgadata_stuffclock", "processRxAudio", "processTxAudio",
                   "initAudioProcessor", "FFT_Init", "FFT_doFFT", "ddc_legacy_shutdown", "dc_filter", "DoAGC",
-                  "processNoiseReduction", "CWDecoder_Process", "TRX_DoAutoGain"):
+                  "processNoiseReduction", "CWDecoder_Process", "TRX_DoAutoGain", "TRX_setMode"):
             getattr(L, f).restype = None
         self.TRX = TrxSettings.in_dll(L, "TRX")
 

@@ -336,3 +336,33 @@ def test_smeter_dbm_matches_oracle(ddc, orc):
         a.rx(spec[c], voice[c])
         assert d.smeter_dbm(c) == a.smeter_dbm()
         assert d.audio_status(c)["smeter_max"] == 0.0
+
+
+def test_usb_audio_frames_match_oracle(ddc, orc):
+    """ddc_audio_usb_frames(_dev) (audio_processor.c:415-432) on the codec frames of a real
+    RX block and on hand-made extremes, one volume per channel incl. 0, 1, 100 and 255."""
+    torch = pytest.importorskip("torch")
+    vols = [50, 1, 100, 0, 255, 20, 33]
+    n_ch, n = len(vols), 192 * 6
+    spec, voice = make_inputs(n_ch, n, 900)
+    d = ddc.Ddc(n_ch)
+    for c, v in enumerate(vols):
+        d.audio_configure(ddc.audio_params(mode="USB", volume=v, agc=0, rf_gain=250.0), channel=c)
+    audio = d.audio_rx_process(spec, voice)
+    rng = np.random.default_rng(5)
+    audio[:, :64] = rng.integers(-2 ** 31, 2 ** 31, size=(n_ch, 64, 2), dtype=np.int64).astype(np.int32)
+    audio[:, 64:70] = np.array([[2 ** 31 - 1, -2 ** 31], [0, 1], [-1, 16383], [32767, -32768], [65535, 40000],
+                                [-40000, 7]], np.int32)
+    got = d.audio_usb_frames(audio)
+    for c, v in enumerate(vols):
+        assert np.array_equal(got[c], orc.usb_frames(audio[c], v)), "volume %d" % v
+    # device-pointer form, after a volume change through ddc_audio_update
+    d.audio_update(ddc.audio_params(mode="USB", volume=10, agc=0, rf_gain=250.0), channel=0)
+    a_dev = torch.from_numpy(audio).cuda()
+    u_dev = torch.zeros((n_ch, n, 2), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    d.audio_usb_frames_dev(a_dev.data_ptr(), n, u_dev.data_ptr())
+    d.sync()
+    assert np.array_equal(u_dev[0].cpu().numpy(), orc.usb_frames(audio[0], 10))
+    assert np.array_equal(u_dev[1:].cpu().numpy(), got[1:])
+    d.close()

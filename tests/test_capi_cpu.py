@@ -170,3 +170,34 @@ def test_legacy_autogain_drives_the_trx_fields(ddc):
         fw.L.TRX_DoAutoGain()
     assert (fw.TRX.Preamp, fw.TRX.ATT) == (False, False)
     fw.TRX.AutoGain = False
+
+
+def test_mode_policy_is_trx_setmode(ddc, orc):
+    """ddc_audio_params_for_mode against TRX_setMode (trx_manager.c:193-220) for every mode:
+    SSB / DIGI / AM take the SSB width, CW the CW width, NFM the FM width, WFM 0, the rest
+    keep what the VFO had; no other field moves."""
+    import ctypes as C
+    L = ddc.lib()
+    for mode in range(12):
+        p = ddc.audio_params(mode="USB", filter_width=1234, volume=77, notch_fc=900)
+        before = bytes(p)
+        assert L.ddc_audio_params_for_mode(mode, 2700, 500, 15000, C.byref(p)) == 0
+        assert p.mode == mode
+        assert p.filter_width == orc.params_for_mode(mode, 2700, 500, 15000, 1234)
+        p.mode, p.filter_width = 1, 1234
+        assert bytes(p) == before
+    want = {0: 2700, 1: 2700, 2: 1234, 3: 500, 4: 500, 5: 2700, 6: 2700, 7: 1234, 8: 15000, 9: 0, 10: 2700, 11: 1234}
+    assert {m: orc.params_for_mode(m, 2700, 500, 15000, 1234) for m in range(12)} == want
+    p = ddc.audio_params()
+    assert L.ddc_audio_params_for_mode(12, 2700, 500, 15000, C.byref(p)) != 0
+
+
+def test_oracle_usb_frames_known_answers(orc):
+    """audio_processor.c:415-432 by hand: the factor is (1 / Volume) * 100 in float32, the
+    product is cut towards zero, 32-bit saturation comes before the cut to 16 bits."""
+    x = np.array([0, 1000, -1000, 3, -3, 16383, 40000, -40000, 2 ** 31 - 1, -2 ** 31], np.int32)
+    assert list(orc.usb_frames(x, 50)) == [0, 2000, -2000, 6, -6, 32766, 80000 - 65536, 65536 - 80000, -1, 0]
+    assert list(orc.usb_frames(x, 100)[:6]) == [0, 1000, -1000, 3, -3, 16383]
+    g = np.float32(np.float32(1.0) / np.float32(30)) * np.float32(100)
+    assert list(orc.usb_frames(x[:6], 30)) == [((int(np.float32(v) * g) + 32768) % 65536) - 32768 for v in x[:6]]
+    assert list(orc.usb_frames(np.array([0, 5, -5], np.int32), 0)) == [0, -1, 0]   # 0 * inf = NaN -> 0; +-inf saturate

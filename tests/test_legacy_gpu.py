@@ -143,3 +143,50 @@ def test_fine_grained_functions(fw, orc):
     tone = (500 * np.cos(2 * np.pi * 250.0 * np.arange(192) / 48000.0)).astype(np.float32)
     fw.L.CWDecoder_Process(tone.ctypes.data)
     assert fw.err() == ""
+
+
+def test_set_mode_policy_and_usb_buffers(fw, orc):
+    """TRX_setMode hands the VFO the width of the mode (trx_manager.c:193-220) and
+    re-initialises the filters; processRxAudio fills the USB-audio buffer that
+    USB_AUDIO_current_rx_buffer names while USB_AUDIO_need_rx_buffer is up
+    (audio_processor.c:415-432)."""
+    T = fw.TRX
+    T.current_vfo = False
+    T.SSB_Filter, T.CW_Filter, T.FM_Filter = 3000, 300, 10000
+    T.VFO_A.Filter_Width = 1800
+    for mode, want in ((1, 3000), (3, 300), (4, 300), (8, 10000), (9, 0), (2, 0), (10, 3000), (0, 3000), (5, 3000)):
+        fw.L.TRX_setMode(mode)
+        assert fw.err() == ""
+        assert (T.VFO_A.Mode, T.VFO_A.Filter_Width) == (mode, want), mode
+    T.AGC, T.DNR, T.NotchFilter, T.Mute, T.CWDecoder = False, False, False, False, False
+    T.Volume, T.RF_Gain, T.SSB_HPF_pass = 35, 120, 300
+    fw.L.TRX_setMode(1)                      # USB, 3000 Hz
+    assert fw.err() == ""
+    a = orc.Audio(orc.audio_params(mode="USB", filter_width=3000, hpf_pass=300, agc=0, volume=35, rf_gain=120.0))
+    need_rx = fw.var("Processor_NeedRXBuffer", C.c_bool)
+    need_usb = fw.var("USB_AUDIO_need_rx_buffer", C.c_bool)
+    cur_usb = fw.var("USB_AUDIO_current_rx_buffer", C.c_bool)
+    index = fw.var("FPGA_Audio_Buffer_Index", C.c_uint16)
+    usb = {False: fw.arr("USB_AUDIO_rx_buffer_a", C.c_int16, 384), True: fw.arr("USB_AUDIO_rx_buffer_b", C.c_int16, 384)}
+    rings = [fw.arr("FPGA_Audio_Buffer_" + n, C.c_float, 384) for n in ("SPEC_I", "SPEC_Q", "VOICE_I", "VOICE_Q")]
+    frames = (np.stack([sig.noisy_two_tone(384, 40), sig.noisy_two_tone(384, 41)]))
+    for k, which in enumerate((False, True)):
+        blk_s, blk_v = frames[0][192 * k:192 * k + 192], frames[1][192 * k:192 * k + 192]
+        rings[0][:192], rings[1][:192] = blk_s[:, 0], blk_s[:, 1]
+        rings[2][:192], rings[3][:192] = blk_v[:, 0], blk_v[:, 1]
+        index.value = 193                    # the half buffer 0..191 has just filled
+        cur_usb.value = which
+        usb[False][:] = 77
+        usb[True][:] = 77
+        need_usb.value = True
+        need_rx.value = True
+        fw.L.processRxAudio()
+        assert fw.err() == "" and not need_usb.value and not need_rx.value
+        want = a.rx(blk_s, blk_v)
+        assert np.array_equal(usb[which].reshape(192, 2), orc.usb_frames(want, 35))
+        assert np.all(usb[not which] == 77)
+    # without the flag the buffers stay as they are
+    usb[False][:] = 5
+    need_rx.value = True
+    fw.L.processRxAudio()
+    assert np.all(usb[False] == 5)

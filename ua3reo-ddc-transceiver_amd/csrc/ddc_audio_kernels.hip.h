@@ -980,4 +980,44 @@ __global__ void ddc_audio_stage_k(AudioState *__restrict__ states, uint32_t ch, 
     }
 }
 
+
+/*
+ * USB-audio frames of the RX path (STM32/Src/audio_processor.c:415-432): every
+ * int32 entry of the codec buffer becomes one int16,
+ *     (int16_t)((int32_t)Processor_AudioBuffer[i] * (1.0f / TRX.Volume * 100.0f)),
+ * i.e. the volume scaling of :364-374 is taken out again for the USB host.  The
+ * float -> int16 cast is what the Cortex-M4F does with it: vcvt.s32.f32 (towards
+ * zero, saturating, NaN -> 0) and the low 16 bits of that (Volume 0 makes the
+ * factor infinite: 0 stays 0, anything else saturates to 0xFFFF / 0x0000).
+ * audio_lr / usb_lr: [channel][n_frames][2].
+ */
+__device__ __forceinline__ int16_t usb_word(int32_t v, float gain)
+{
+#pragma clang fp contract(off)
+    const float f = (float)v * gain;
+    int32_t i;
+    if (f != f) i = 0;
+    else if (f >= 2147483648.0f) i = 2147483647;
+    else if (f <= -2147483648.0f) i = (-2147483647 - 1);
+    else i = (int32_t)f;
+    return (int16_t)(uint16_t)((uint32_t)i & 0xFFFFu);
+}
+
+__global__ __launch_bounds__(256) void ddc_audio_usb_frames(const AudioState *__restrict__ st, uint32_t n_ch,
+                                                           const int32_t *__restrict__ audio_lr, uint32_t n_frames,
+                                                           int16_t *__restrict__ usb_lr)
+{
+    // one thread per two frames (16 bytes in, 8 bytes out)
+    const uint32_t per_ch = n_frames / 2;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_ch * per_ch) return;
+    const uint32_t ch = (uint32_t)(gid / per_ch);
+    const float gain = (1.0f / (float)st[ch].p.volume) * 100.0f;
+    const int4 v = reinterpret_cast<const int4 *>(audio_lr)[gid];
+    uint2 o;
+    o.x = (uint32_t)(uint16_t)usb_word(v.x, gain) | ((uint32_t)(uint16_t)usb_word(v.y, gain) << 16);
+    o.y = (uint32_t)(uint16_t)usb_word(v.z, gain) | ((uint32_t)(uint16_t)usb_word(v.w, gain) << 16);
+    reinterpret_cast<uint2 *>(usb_lr)[gid] = o;
+}
+
 } // namespace ddc

@@ -15,7 +15,8 @@ extern "C" {
 
 struct TRX_SETTINGS TRX = {
     false, { 7100000, TRX_MODE_LSB, 2700 }, { 14150000, TRX_MODE_USB, 2700 },
-    true, false, false, 3, 50, false, 100, 1, 50, 1, false, 1000, false, true, 500, 4, 300 };
+    true, false, false, 3, 50, false, 100, 1, 50, 1, false, 1000, false, true, 500, 4, 300,
+    false, false, false, false, 500, 2700, 15000 }; // widths: settings.c:54-56
 volatile bool TRX_ptt_hard = false, TRX_ptt_cat = false, TRX_key_serial = false, TRX_key_hard = false, TRX_tune = false,
               TRX_IQ_swap = false;
 volatile bool TRX_ADC_OTR = false, TRX_DAC_OTR = false;
@@ -36,6 +37,8 @@ volatile bool Processor_NeedRXBuffer = false, Processor_NeedTXBuffer = false;
 volatile float32_t Processor_TX_MAX_amplitude = 0.0f, ALC_need_gain = 1.0f;
 volatile float32_t Processor_RX_Audio_Samples_MAX_value = 0.0f, Processor_RX_Audio_Samples_MIN_value = 0.0f;
 float32_t FPGA_Audio_Buffer_Q_tmp[FPGA_AUDIO_BUFFER_HALF_SIZE], FPGA_Audio_Buffer_I_tmp[FPGA_AUDIO_BUFFER_HALF_SIZE];
+int16_t USB_AUDIO_rx_buffer_a[USB_AUDIO_RX_BUFFER_SIZE / 2], USB_AUDIO_rx_buffer_b[USB_AUDIO_RX_BUFFER_SIZE / 2];
+volatile bool USB_AUDIO_current_rx_buffer = false, USB_AUDIO_need_rx_buffer = false;
 
 volatile uint32_t FFT_buff_index = 0;
 bool NeedFFTInputBuffer = false, FFT_need_fft = true;
@@ -185,6 +188,18 @@ size_t ddc_legacy_dac_pop(uint16_t *dac, size_t n)
 
 VFO *CurrentVFO(void) { return TRX.current_vfo ? &TRX.VFO_B : &TRX.VFO_A; }
 uint8_t TRX_getMode(void) { return CurrentVFO()->Mode; }
+
+// trx_manager.c:193-220 (the loopback start, LCD and settings-save flags are the firmware's own business)
+void TRX_setMode(uint8_t _mode)
+{
+    CurrentVFO()->Mode = _mode;
+    ddc_audio_params p;
+    memset(&p, 0, sizeof p);
+    p.filter_width = CurrentVFO()->Filter_Width;
+    if (ddc_audio_params_for_mode(_mode, TRX.SSB_Filter, TRX.CW_Filter, TRX.FM_Filter, &p) == 0)
+        CurrentVFO()->Filter_Width = p.filter_width;
+    ReinitAudioFilters();
+}
 
 static ddc_autogain g_autogain;
 void TRX_DoAutoGain(void)
@@ -343,6 +358,10 @@ void processRxAudio(void)
     memcpy(dst, out, sizeof out);
     Processor_AudioBuffer_ReadyBuffer = Processor_AudioBuffer_ReadyBuffer == 0 ? 1 : 0;
     for (int i = 0; i < 192; i++) { FPGA_Audio_Buffer_I_tmp[i] = (float)out[i][0]; FPGA_Audio_Buffer_Q_tmp[i] = (float)out[i][1]; }
+    if (USB_AUDIO_need_rx_buffer) { // audio_processor.c:415-432
+        int16_t *usb = USB_AUDIO_current_rx_buffer ? USB_AUDIO_rx_buffer_b : USB_AUDIO_rx_buffer_a;
+        if (check(ddc_audio_usb_frames(g_ctx, &out[0][0], 192, usb))) USB_AUDIO_need_rx_buffer = false;
+    }
     pull_status();
     ddc_legacy_tick_ms = ddc_legacy_tick_ms + 4;
     Processor_NeedRXBuffer = false;

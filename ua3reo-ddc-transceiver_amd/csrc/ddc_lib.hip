@@ -782,6 +782,31 @@ int ddc_profile_collect(ddc_ctx *ctx, double *front_ms, double *tail_ms, uint32_
 
 /* ---- audio path and panadapter ---------------------------------------------- */
 
+int ddc_audio_params_for_mode(uint8_t mode, uint16_t ssb_filter, uint16_t cw_filter, uint16_t fm_filter,
+                              ddc_audio_params *p)
+{
+    if (!p) return -EINVAL;
+    if (mode > DDC_MODE_LOOPBACK) return fail(nullptr, -EINVAL, "no such mode");
+    p->mode = mode;
+    switch (mode) { // trx_manager.c:197-216
+    case DDC_MODE_LSB: case DDC_MODE_USB: case DDC_MODE_DIGI_L: case DDC_MODE_DIGI_U: case DDC_MODE_AM:
+        p->filter_width = ssb_filter;
+        break;
+    case DDC_MODE_CW_L: case DDC_MODE_CW_U:
+        p->filter_width = cw_filter;
+        break;
+    case DDC_MODE_NFM:
+        p->filter_width = fm_filter;
+        break;
+    case DDC_MODE_WFM:
+        p->filter_width = 0;
+        break;
+    default: // IQ, NO_TX, LOOPBACK: the firmware leaves the VFO's width as it is
+        break;
+    }
+    return 0;
+}
+
 int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p)
 {
     int rc = check_channel(ctx, channel);
@@ -918,6 +943,26 @@ int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t
     return 0;
 }
 
+int ddc_audio_usb_frames_dev(ddc_ctx *ctx, const int32_t *audio_lr, size_t n_frames, int16_t *usb_lr)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!audio_lr || !usb_lr) return fail(ctx, -EINVAL, "null buffer");
+    if (n_frames % 2) return fail(ctx, -EINVAL, "n_frames must be even");
+    if (n_frames > 0xFFFFFF00u) return fail(ctx, -EINVAL, "n_frames too large");
+    if (((uintptr_t)audio_lr % 16) || ((uintptr_t)usb_lr % 8))
+        return fail(ctx, -EINVAL, "audio_lr must be 16-byte aligned, usb_lr 8-byte aligned");
+    int rc = audio_all_ready(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    const uint64_t items = (uint64_t)ctx->cfg.n_channels * (n_frames / 2);
+    if (items >= (1ull << 39)) return fail(ctx, -EINVAL, "too many frames in one call");
+    hipLaunchKernelGGL(ddc::ddc_audio_usb_frames, dim3((uint32_t)((items + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->d_audio, ctx->cfg.n_channels, audio_lr, (uint32_t)n_frames, usb_lr);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 static int ensure_stage(ddc_ctx *ctx, int slot, size_t bytes)
 {
     if (bytes <= ctx->stage_cap[slot]) return 0;
@@ -946,6 +991,23 @@ int ddc_audio_rx_process(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t *vo
                                   (int32_t *)ctx->d_stage[2]);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(audio_lr, ctx->d_stage[2], out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ddc_audio_usb_frames(ddc_ctx *ctx, const int32_t *audio_lr, size_t n_frames, int16_t *usb_lr)
+{
+    if (!ctx) return -EINVAL;
+    if (n_frames == 0) return 0;
+    if (!audio_lr || !usb_lr) return fail(ctx, -EINVAL, "null buffer");
+    const size_t n = (size_t)ctx->cfg.n_channels * n_frames * 2;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, n * sizeof(int32_t))) || (rc = ensure_stage(ctx, 1, n * sizeof(int16_t)))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_stage[0], audio_lr, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = ddc_audio_usb_frames_dev(ctx, (const int32_t *)ctx->d_stage[0], n_frames, (int16_t *)ctx->d_stage[1]);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(usb_lr, ctx->d_stage[1], n * sizeof(int16_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

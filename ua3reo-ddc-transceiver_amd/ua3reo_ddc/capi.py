@@ -119,6 +119,9 @@ def lib():
     L.ddc_fft_move_waterfall.argtypes = [vp, i32, i32]
     L.ddc_audio_stage.argtypes = [vp, i32, C.c_int, C.c_int, vp, C.c_int]
     L.ddc_audio_rx_process_dev.argtypes = [vp, vp, vp, sz, vp]
+    L.ddc_audio_usb_frames_dev.argtypes = [vp, vp, sz, vp]
+    L.ddc_audio_usb_frames.argtypes = [vp, vp, sz, vp]
+    L.ddc_audio_params_for_mode.argtypes = [C.c_uint8, C.c_uint16, C.c_uint16, C.c_uint16, vp]
     L.ddc_audio_rx_process.argtypes = [vp, vp, vp, sz, vp]
     L.ddc_fft_process_dev.argtypes = [vp, vp, sz, vp, vp]
     L.ddc_fft_process.argtypes = [vp, vp, sz, vp, vp]
@@ -307,6 +310,17 @@ class Ddc:
         out = np.zeros(s.shape, np.int32)
         self._check(self._L.ddc_audio_rx_process(self._h, _np_ptr(s), _np_ptr(v), s.shape[1], _np_ptr(out)))
         return out
+
+    def audio_usb_frames(self, audio_lr):
+        """int32 [n_channels][n_frames][2] (host) -> the int16 USB-audio frames of the same shape."""
+        a = np.ascontiguousarray(audio_lr, dtype=np.int32)
+        assert a.ndim == 3 and a.shape[0] == self.n_channels and a.shape[2] == 2
+        out = np.zeros(a.shape, np.int16)
+        self._check(self._L.ddc_audio_usb_frames(self._h, _np_ptr(a), a.shape[1], _np_ptr(out)))
+        return out
+
+    def audio_usb_frames_dev(self, audio_ptr, n_frames, usb_ptr):
+        self._check(self._L.ddc_audio_usb_frames_dev(self._h, audio_ptr, n_frames, usb_ptr))
 
     def audio_rx_process_dev(self, spec_ptr, voice_ptr, n_frames, audio_ptr):
         self._check(self._L.ddc_audio_rx_process_dev(self._h, spec_ptr, voice_ptr, n_frames, audio_ptr))
