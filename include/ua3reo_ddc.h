@@ -153,7 +153,11 @@ int ddc_profile_collect(ddc_ctx *ctx, double *front_ms, double *tail_ms, uint32_
 void ddc_pack_rx_frames(const int16_t *spec_iq, const int16_t *voice_iq, size_t n_frames, uint8_t *out);
 void ddc_unpack_tx_frames(const uint8_t *in, size_t n_frames, int16_t *tx_iq);
 void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_inc22);
-/* Applies a command-1 payload to a channel: tuning word and RX/TX direction. */
+/* Applies a command-1 payload to a channel (-1 = all): the tuning word, and the RX/TX
+ * flag as the FPGA uses it (clock enable of one direction, reset of the other): when
+ * the flag differs from the channel's last one, the direction that is switched on is
+ * reset to zero state (ddc_tx_reset / ddc_rx_reset).  A ctx starts in RX.  The preamp
+ * bit belongs to the RF unit and is ignored. */
 int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4]);
 
 /* Status frame: command 2 reply of the bus (FPGA/stm32_interface.v:172-205), read

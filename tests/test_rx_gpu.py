@@ -230,6 +230,14 @@ def test_state_save_restore_resumes_bit_exact(ddc, orc):
     a1 = d.audio_rx_process(np.tile(s1, (1, 32, 1)), np.tile(v1, (1, 32, 1)))
     a2 = e.audio_rx_process(np.tile(s2, (1, 32, 1)), np.tile(v2, (1, 32, 1)))
     assert np.array_equal(a1, a2)
+    # the restored host mirror of the tuning words is in the device format: retuning one
+    # channel of the restored ctx leaves the other one's word alone
+    e.tune(1, 70001)
+    e.rx_reset(-1)
+    s3, v3 = e.rx_process(rows_a, samples)
+    for c, phi in enumerate((phis[0], 70001)):
+        ws, wv = orc.RxChain(phi).run(adc[c][:samples])
+        assert np.array_equal(s3[c], ws) and np.array_equal(v3[c], wv), c
     with pytest.raises(ddc.DdcError):
         ddc.Ddc(3).state_restore(blob)
     # a blob of another layout version (header word 1), a damaged magic and a short blob are refused
@@ -405,3 +413,38 @@ def test_shared_adc_stream_fans_out_to_all_channels(ddc, orc):
     e.rx_process_dev(row.data_ptr(), 0, samples, s2.data_ptr(), v2.data_ptr())
     e.sync()
     assert np.array_equal(s2.cpu().numpy(), outs[0][0]) and np.array_equal(v2.cpu().numpy(), outs[0][1])
+
+
+def test_set_params_direction_flip_resets_the_entered_direction(ddc, orc):
+    """A command-1 frame with the TX bit holds RX in reset and starts TX from zero; the
+    frame that clears it restarts RX from zero (FPGA/stm32_interface.v:142-171,
+    clk_enable / reset wiring of FPGA/UA3REO.bdf).  A frame that keeps the direction only
+    retunes."""
+    samples = 1024 * 4
+    rng = np.random.default_rng(17)
+    adc = rng.integers(-2048, 2048, size=(2, 2 * samples)).astype(np.int16)
+    rows = [np.stack([ddc.pack_adc12(a[k * samples:(k + 1) * samples]) for a in adc]) for k in range(2)]
+    phi = 605867
+    frame = lambda tx, w: np.array([(8 if tx else 0), (w >> 16) & 0x3F, (w >> 8) & 0xFF, w & 0xFF], np.uint8)
+    d = ddc.Ddc(2)
+    d.set_params(frame(False, phi))
+    s0, v0 = d.rx_process(rows[0], samples)
+    d.set_params(frame(False, phi))              # same direction: state runs on
+    s1, v1 = d.rx_process(rows[1], samples)
+    ws, wv = orc.RxChain(phi).run(adc[0])
+    assert np.array_equal(np.concatenate([s0[0], s1[0]]), ws) and np.array_equal(np.concatenate([v0[0], v1[0]]), wv)
+    iq = rng.integers(-20000, 20000, size=(2, 6, 2)).astype(np.int16)
+    d.set_params(frame(True, phi), channel=1)    # channel 1 goes to TX ...
+    dac_a = d.tx_process(iq)
+    d.set_params(frame(True, phi), channel=1)    # ... stays there: TX state runs on
+    dac_b = d.tx_process(iq)
+    want = orc.TxChain(phi).run(np.concatenate([iq[1], iq[1]]))
+    assert np.array_equal(np.concatenate([dac_a[1], dac_b[1]]).view(np.uint16), want)
+    d.set_params(frame(False, phi), channel=1)   # ... and back: its RX restarts from power-on state
+    s2, v2 = d.rx_process(rows[0], samples)
+    ws1, wv1 = orc.RxChain(phi).run(adc[1][:samples])
+    assert np.array_equal(s2[1], ws1) and np.array_equal(v2[1], wv1)
+    # channel 0 never left RX: its third call continues the stream (fed the first row again)
+    ws0, wv0 = orc.RxChain(phi).run(np.concatenate([adc[0], adc[0][:samples]]))
+    assert np.array_equal(s2[0], ws0[2 * samples // 1024:]) and np.array_equal(v2[0], wv0[2 * samples // 1024:])
+    d.close()

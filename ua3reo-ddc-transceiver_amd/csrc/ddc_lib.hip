@@ -48,6 +48,7 @@ struct ddc_ctx {
     int16_t *d_out = nullptr;
     size_t out_cap = 0;
     std::vector<uint32_t> h_phi;
+    std::vector<uint8_t> tx_dir;       // per channel: last direction a command-1 frame set (0 = RX, the power-on state)
     // ADC_MIN / ADC_MAX registers of the status frame, gathered only when enabled
     bool adc_stats = false;
     int *d_adc_min = nullptr, *d_adc_max = nullptr;
@@ -316,6 +317,7 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_bit1), bit1, sizeof bit1));
     }
     ctx->h_phi.assign(nch, 0);
+    ctx->tx_dir.assign(nch, 0);
     {
         // power-on values of the registers (FPGA/stm32_interface.v:385-388)
         std::vector<int> lo(nch, 2000), hi(nch, -2000);
@@ -680,6 +682,7 @@ int ddc_tx_process_dev(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t
     if (n_iq > (1u << 21) || nch * (2 * n_iq + 1) >= (1ull << 31))
         return fail(ctx, -EINVAL, "too many TX samples in one call");
     const uint32_t n48 = (uint32_t)n_iq, n96 = 2 * n48;
+    if ((unsigned long long)nch * n96 >= (1ull << 26)) return fail(ctx, -EINVAL, "more than 2^26 blocks of 512 DAC samples in one call");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     ddc_tx_state &tx = ctx->tx;
     if (n48 > tx.cap48) {
@@ -692,7 +695,6 @@ int ddc_tx_process_dev(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t
     ddc::ddc_tx_load_history<<<(uint32_t)nch, 64, 0, st>>>(tx.d_hist_y, tx.d_ybuf, n96);
     const uint32_t nfr = (uint32_t)(nch * n48);
     ddc::ddc_tx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(iq48k, tx.d_hist_x, n48, (uint32_t)nch, tx.d_ybuf);
-    if ((unsigned long long)nch * n96 >= (1ull << 26)) return fail(ctx, -EINVAL, "more than 2^26 blocks of 512 DAC samples in one call");
     const uint32_t total = (uint32_t)(nch * n96);
     ddc::ddc_tx_duc<<<(total + 255) / 256, 256, 0, st>>>(tx.d_ybuf, n96, total, tx.d_acc, ctx->d_phi, dac14,
                                                         ctx->d_nco_tab);
@@ -852,7 +854,7 @@ int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p
         st.cw_limit_low = 50;
         memset(st.cw_text, ' ', 15);
     }
-    static ddc::ZoomState zs; // 4 KB: not on the stack of a small-stack caller
+    static thread_local ddc::ZoomState zs; // 4 KB: not on the stack of a small-stack caller; per thread, ctxs may be configured concurrently
     memset(&zs, 0, sizeof zs);
     zs.zoom = p->fft_zoom > 1 ? p->fft_zoom : 1;
     if (zs.zoom > 1) { // FFT_Init, fft.c:188-209
@@ -862,7 +864,7 @@ int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p
         for (int i = 0; i < 20; i++) zs.c[i] = (float)kZoomBiquad[zi][i];
         for (int i = 0; i < 4; i++) zs.fir[i] = (float)kZoomFir[zi][i];
     }
-    static ddc::TxAudioState ts;
+    static thread_local ddc::TxAudioState ts;
     memset(&ts, 0, sizeof ts);
     ts.alc_gain = 1.0f;
     ts.fm_index = 2.0f; // ModulateFM, audio_processor.c:597-606
@@ -1337,7 +1339,7 @@ namespace {
 struct StateSeg { void *dev; size_t bytes; };
 struct StateHeader { uint32_t magic, version, n_channels, n_seg; uint64_t total; };
 constexpr uint32_t kStateMagic = 0x43444455u; // "UDDC"
-constexpr uint32_t kStateVersion = 2;          // 2: window moments and mixer carries hold twice the CIC input
+constexpr uint32_t kStateVersion = 3;          // 2: window moments and mixer carries hold twice the CIC input; 3: + RX/TX direction
 
 std::vector<StateSeg> state_segments(ddc_ctx *ctx)
 {
@@ -1358,7 +1360,7 @@ std::vector<StateSeg> state_segments(ddc_ctx *ctx)
 size_t ddc_state_size(ddc_ctx *ctx)
 {
     if (!ctx) return 0;
-    size_t t = sizeof(StateHeader) + ctx->cfg.n_channels * (2 + sizeof(ddc_audio_params)); // + audio_ready, zoom_of, audio_cfg
+    size_t t = sizeof(StateHeader) + ctx->cfg.n_channels * (3 + sizeof(ddc_audio_params)); // + audio_ready, zoom_of, tx_dir, audio_cfg
     for (const StateSeg &g : state_segments(ctx)) t += g.bytes;
     return t;
 }
@@ -1381,7 +1383,8 @@ int ddc_state_save(ddc_ctx *ctx, void *buf, size_t size)
     }
     memcpy(p, ctx->audio_ready.data(), ctx->cfg.n_channels);
     memcpy(p + ctx->cfg.n_channels, ctx->zoom_of.data(), ctx->cfg.n_channels);
-    memcpy(p + 2 * (size_t)ctx->cfg.n_channels, ctx->audio_cfg.data(), ctx->cfg.n_channels * sizeof(ddc_audio_params));
+    memcpy(p + 2 * (size_t)ctx->cfg.n_channels, ctx->tx_dir.data(), ctx->cfg.n_channels);
+    memcpy(p + 3 * (size_t)ctx->cfg.n_channels, ctx->audio_cfg.data(), ctx->cfg.n_channels * sizeof(ddc_audio_params));
     return 0;
 }
 
@@ -1405,13 +1408,14 @@ int ddc_state_restore(ddc_ctx *ctx, const void *buf, size_t size)
     }
     memcpy(ctx->audio_ready.data(), p, ctx->cfg.n_channels);
     memcpy(ctx->zoom_of.data(), p + ctx->cfg.n_channels, ctx->cfg.n_channels);
-    memcpy(ctx->audio_cfg.data(), p + 2 * (size_t)ctx->cfg.n_channels, ctx->cfg.n_channels * sizeof(ddc_audio_params));
+    memcpy(ctx->tx_dir.data(), p + 2 * (size_t)ctx->cfg.n_channels, ctx->cfg.n_channels);
+    memcpy(ctx->audio_cfg.data(), p + 3 * (size_t)ctx->cfg.n_channels, ctx->cfg.n_channels * sizeof(ddc_audio_params));
     ctx->fft_zoom_all = ctx->zoom_of[0];
     for (uint8_t zv : ctx->zoom_of) if (zv != ctx->zoom_of[0]) ctx->fft_zoom_all = 0;
     // the host mirror of the tuning words
     std::vector<uint32_t> phi(ctx->cfg.n_channels);
     HIP_TRY(ctx, hipMemcpy(phi.data(), ctx->d_phi, phi.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t c = 0; c < phi.size(); c++) ctx->h_phi[c] = phi[c] >> 10;
+    for (size_t c = 0; c < phi.size(); c++) ctx->h_phi[c] = phi[c]; // device format: tuning word << 10
     return 0;
 }
 
@@ -1449,8 +1453,19 @@ int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
     int tx = 0, pre = 0;
     uint32_t phi = 0;
     ddc_parse_params(in, &tx, &pre, &phi);
-    (void)pre;
-    (void)tx;
+    (void)pre; // the preamp relay is the RF unit's business
+    int rc = check_channel(ctx, channel);
+    if (rc) return rc;
+    // rx/tx flag (FPGA/stm32_interface.v:142-171): clk_enable of one direction, reset of
+    // the other, so the direction that is switched on starts from zero state
+    const uint32_t lo = channel < 0 ? 0 : (uint32_t)channel;
+    const uint32_t hi = channel < 0 ? ctx->cfg.n_channels : (uint32_t)channel + 1;
+    for (uint32_t c = lo; c < hi; c++) {
+        if ((ctx->tx_dir[c] != 0) == (tx != 0)) continue;
+        rc = tx ? ddc_tx_reset(ctx, (int32_t)c) : ddc_rx_reset(ctx, (int32_t)c);
+        if (rc) return rc;
+        ctx->tx_dir[c] = tx ? 1 : 0;
+    }
     return ddc_tune(ctx, channel, phi);
 }
 

@@ -295,9 +295,9 @@ inline int ddc_tx_state_create(ddc_tx_state *s, uint32_t n_channels, hipStream_t
     if (hipMalloc(&s->d_acc, n * 4) != hipSuccess) return -12;
     if (hipMalloc(&s->d_hist_x, n * ddc::kTxXHist * 4) != hipSuccess) return -12;
     if (hipMalloc(&s->d_hist_y, n * ddc::kTxYHist * 4) != hipSuccess) return -12;
-    (void)hipMemsetAsync(s->d_acc, 0, n * 4, st);
-    (void)hipMemsetAsync(s->d_hist_x, 0, n * ddc::kTxXHist * 4, st);
-    (void)hipMemsetAsync(s->d_hist_y, 0, n * ddc::kTxYHist * 4, st);
+    if (hipMemsetAsync(s->d_acc, 0, n * 4, st) != hipSuccess) return -5;
+    if (hipMemsetAsync(s->d_hist_x, 0, n * ddc::kTxXHist * 4, st) != hipSuccess) return -5;
+    if (hipMemsetAsync(s->d_hist_y, 0, n * ddc::kTxYHist * 4, st) != hipSuccess) return -5;
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_tx_p1), tx_ciccomp_p1, sizeof tx_ciccomp_p1, 0,
                                hipMemcpyHostToDevice, st) != hipSuccess) return -5;
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_tx_p2), tx_ciccomp_p2, sizeof tx_ciccomp_p2, 0,

@@ -381,6 +381,12 @@ class Ddc:
         self._check(self._L.ddc_get_status(self._h, channel, _np_ptr(out)))
         return out
 
+    def set_params(self, frame, channel=-1):
+        """Command-1 payload (4 bytes: flags, tuning word) for one channel or all."""
+        b = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert b.size == 4
+        self._check(self._L.ddc_set_params(self._h, channel, _np_ptr(b)))
+
     def state_save(self):
         n = self._L.ddc_state_size(self._h)
         buf = np.zeros(n, np.uint8)
