@@ -366,3 +366,64 @@ def test_usb_audio_frames_match_oracle(ddc, orc):
     assert np.array_equal(u_dev[0].cpu().numpy(), orc.usb_frames(audio[0], 10))
     assert np.array_equal(u_dev[1:].cpu().numpy(), got[1:])
     d.close()
+
+
+def test_config3_chain_256_channels_ddc_into_panadapter(ddc, orc):
+    """BASELINE config 3 at its shape: 256 tuned channels x 2^20 ADC samples through
+    ddc_rx_process_dev -> ddc_fft_process_dev on device buffers (two panadapter rows per
+    channel).  One call equals two half calls for every channel, bit for bit, and
+    channels 0, 127 and 255 match the oracle chain (SPEC exactly, bins within 1e-4 of the
+    frame maximum, colour rows up to boundary pixels)."""
+    torch = pytest.importorskip("torch")
+    n_ch, samples = 256, 1 << 20
+    rb = samples // 2 * 3
+    nf = samples // 1024
+    probe = (0, 127, 255)
+    g = torch.Generator(device="cuda").manual_seed(303)
+    adc = torch.randint(0, 256, (n_ch, rb), dtype=torch.uint8, device="cuda", generator=g)
+    host = {c: ddc.synth_adc(c, samples) for c in probe}
+    for c in probe:
+        adc[c] = torch.from_numpy(ddc.pack_adc12(host[c])).cuda()
+    phis = [ddc.phrase_from_frequency(1000000 + 48000 * c)[0] for c in range(n_ch)]
+    params = dict(mode="USB", fft_averaging=4)
+
+    def run(parts):
+        d = ddc.Ddc(n_ch)
+        d.tune_many(phis)
+        d.audio_configure(ddc.audio_params(**params))
+        spec = torch.zeros((n_ch, nf, 2), dtype=torch.int16, device="cuda")
+        voice = torch.zeros_like(spec)
+        bins = torch.zeros((n_ch, nf // 512, 256), dtype=torch.float32, device="cuda")
+        rows = torch.zeros((n_ch, nf // 512, 256), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        step, fstep = samples // parts, nf // parts
+        for k in range(parts):
+            # each part's outputs are compact [channel][frames of the part]: stage them, then place them
+            s_k = torch.zeros((n_ch, fstep, 2), dtype=torch.int16, device="cuda")
+            v_k = torch.zeros_like(s_k)
+            b_k = torch.zeros((n_ch, fstep // 512, 256), dtype=torch.float32, device="cuda")
+            r_k = torch.zeros((n_ch, fstep // 512, 256), dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()
+            d.rx_process_dev(adc.data_ptr() + k * (step // 2 * 3), rb, step, s_k.data_ptr(), v_k.data_ptr())
+            d.fft_process_dev(s_k.data_ptr(), fstep, b_k.data_ptr(), r_k.data_ptr())
+            d.sync()
+            spec[:, k * fstep:(k + 1) * fstep] = s_k
+            bins[:, k * (fstep // 512):(k + 1) * (fstep // 512)] = b_k
+            rows[:, k * (fstep // 512):(k + 1) * (fstep // 512)] = r_k
+        d.close()
+        return spec.cpu().numpy(), bins.cpu().numpy(), rows.cpu().numpy().view(np.uint16)
+
+    s1, b1, r1 = run(1)
+    s2, b2, r2 = run(2)
+    assert np.array_equal(s1, s2) and np.array_equal(b1, b2) and np.array_equal(r1, r2)
+    assert np.isfinite(b1).all() and b1.max() > 0
+    bad_pixels = 0
+    for c in probe:
+        ws, _ = orc.RxChain(phis[c]).run(host[c])
+        assert np.array_equal(s1[c], ws), c
+        a = orc.Audio(orc.audio_params(**params))
+        for f in range(nf // 512):
+            wb, wr, _ = a.fft(ws[512 * f:512 * (f + 1)])
+            assert np.abs(b1[c, f] - wb).max() <= 1e-4 * max(float(wb.max()), 1e-3), (c, f)
+            bad_pixels += int((r1[c, f] != wr).sum())
+    assert bad_pixels <= 4
