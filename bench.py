@@ -9,29 +9,32 @@ HBM.  Workload per GPU: the per-GPU shard of BASELINE config 5
 the decimated SPEC+VOICE I/Q, as that config prescribes.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 4            # starts 4 ranks itself, one per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  `--dry-run-gloo` rehearses the multi-rank plumbing
+(launch, rendezvous, double-buffered all-gather, JSON) on CPUs with a pattern in
+place of the kernels; its numbers mean nothing.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "ua3reo-ddc-transceiver_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 METRIC = "ADC MSamples/s ingested per node, N-channel DDC; % HBM roofline"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 BYTES_PER_CHANNEL_SAMPLE = 1.5 + 8.0 / 1024.0  # packed ADC read + SPEC/VOICE int16 I/Q written
 FS_ADC = 49152000
+N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
+FRONT_SOURCE = os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_rx_kernels.hip.h")
 
 
 class _StdoutToStderr:
@@ -48,94 +51,7 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
-def synth_rows(n_channels, samples, chan0, device, seed):
-    """Packed 12-bit rows [n_channels][samples*3/2] on the device: per channel two
-    tones (1400 and 300 LSB) at f_c = 1 MHz + 48 kHz*channel and +1 kHz, plus
-    uniform noise in [-64, 63], clipped to +-2047."""
-    rb = samples // 2 * 3
-    out = torch.empty((n_channels, rb), dtype=torch.uint8, device=device)
-    g = torch.Generator(device=device).manual_seed(seed)
-    n = torch.arange(samples, device=device, dtype=torch.int64)
-    step = 32
-    for c0 in range(0, n_channels, step):
-        c1 = min(n_channels, c0 + step)
-        ch = torch.arange(chan0 + c0, chan0 + c1, device=device, dtype=torch.int64)[:, None]
-        f1 = 1000000 + 48000 * ch
-        ph1 = ((n[None, :] * f1) % FS_ADC).to(torch.float64) * (2.0 * np.pi / FS_ADC)
-        ph2 = ((n[None, :] * (f1 + 1000)) % FS_ADC).to(torch.float64) * (2.0 * np.pi / FS_ADC)
-        x = torch.round(1400.0 * torch.sin(ph1) + 300.0 * torch.sin(ph2)).to(torch.int32)
-        del ph1, ph2
-        x += torch.randint(-64, 64, x.shape, device=device, generator=g, dtype=torch.int32)
-        x.clamp_(-2047, 2047)
-        x &= 0xFFF
-        s0, s1 = x[:, 0::2], x[:, 1::2]
-        blk = out[c0:c1].view(c1 - c0, samples // 2, 3)
-        blk[:, :, 0] = (s0 & 0xFF).to(torch.uint8)
-        blk[:, :, 1] = ((s0 >> 8) | ((s1 & 0xF) << 4)).to(torch.uint8)
-        blk[:, :, 2] = (s1 >> 4).to(torch.uint8)
-        del x, s0, s1
-    return out
-
-
-def measured_traffic(nch, samples):
-    """HBM-side bytes per ddc_rx_front launch from the last committed PMC passes
-    (FETCH_SIZE doubled as gfx950 needs, plus WRITE_SIZE), if they were taken on
-    this workload shape; rocprofv3 counters cannot be read from inside the run."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)
-        if t["channels"] == nch and t["samples"] == samples:
-            return float(t["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
-
-
-def cpu_baseline(n_threads, samples=1 << 22, distinct=4, reps=24):
-    """The CPU oracle (C restatement of the reference datapath, built here with
-    gcc -O3 -march=native) on a bounded sample of the same workload: every thread
-    runs the whole RX chain over `distinct` synthetic channels of `samples` samples,
-    `reps` times.  The timed variant is the window form of mixer + rx_cic, whose lane
-    loops the compiler vectorises (oracle/ddc_oracle.c, orc_fast_rx_front_run); it
-    has to reproduce the clock-level model bit for bit before it is timed.  Also
-    times one thread alone, and the clock-level model on one thread."""
-    import tempfile
-    import ua3reo_ddc
-    from oracle import oracle
-    L = oracle.build_native_variant(tempfile.mkdtemp(prefix="ddc_oracle_"))
-    rows = [ua3reo_ddc.pack_adc12(ua3reo_ddc.synth_adc(c, samples)) for c in range(distinct)]
-    phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * c)[0] for c in range(distinct)]
-    rb = len(rows[0])
-    packed = np.concatenate(rows)
-    # same answers as the clock-level model of the default build before any timing
-    a = oracle.rx_chain_packed(packed, rb, distinct, 1 << 17, phis, L=L, fast=True)
-    b = oracle.rx_chain_packed(packed, rb, distinct, 1 << 17, phis)
-    if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
-        raise SystemExit("bench: the vectorised CPU chain disagrees with the clock-level oracle")
-
-    def work(_):
-        for _r in range(reps):
-            oracle.rx_chain_packed(packed, rb, distinct, samples, phis, L=L, fast=True)
-
-    t0 = time.perf_counter()
-    oracle.rx_chain_packed(packed, rb, 1, samples, phis, L=L)
-    clock_one = samples / (time.perf_counter() - t0) / 1e6
-    best = 0.0
-    for _r in range(3):
-        t0 = time.perf_counter()
-        oracle.rx_chain_packed(packed, rb, distinct, samples, phis, L=L, fast=True)
-        best = max(best, distinct * samples / (time.perf_counter() - t0) / 1e6)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(n_threads) as ex:
-        list(ex.map(work, range(n_threads)))
-    dt = time.perf_counter() - t0
-    total = n_threads * reps * distinct * samples
-    return total / dt / 1e6, best, "%d threads x %d channel-passes x %d samples, oracle/ddc_oracle.c window form " \
-        "(gcc -O3 -march=native, lanes = 16 windows, bit-exact vs the clock-level model, which runs %.0f MS/s on one " \
-        "thread); host reports %d CPUs" % (n_threads, reps * distinct, samples, clock_one, os.cpu_count() or 0)
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -153,17 +69,160 @@ def main():
                     help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
                          "reported apart from the headline: the ADC bytes then come from L2, not HBM")
     ap.add_argument("--force-gather", action="store_true",
-                    help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU; "
-                         "needs a torch.distributed launch)")
-    args = ap.parse_args()
+                    help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU)")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="no GPU: gloo ranks on CPUs, a pattern instead of the kernels; checks launch + gather + JSON")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks of this script (fresh processes; this
+    parent has not touched the GPU and only waits), pass rank 0's JSON line through and
+    fail if any rank fails."""
+    import socket
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+def source_hash():
+    with open(FRONT_SOURCE, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def load_profile(name, nch, samples):
+    """A committed PMC summary (profiles/<name>) if it was taken on this workload shape AND on
+    the ingest kernel source that is in the tree now; rocprofv3 counters cannot be read from
+    inside the run, so a summary of an older kernel is not replayed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            t = json.load(f)
+        if t["channels"] == nch and t["samples"] == samples and t.get("kernel_source_sha256_16") == source_hash():
+            return t
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (C restatement of the reference datapath, built here with
+    gcc -O3 -march=native -fopenmp) on a bounded sample of the same workload: the
+    window form of mixer + rx_cic with sixteen windows in the CPU's vector lanes
+    (oracle/ddc_oracle.c, orc_fast_rx_front_run) and the 96 / 48 kHz stages of the
+    scalar oracle, one channel per OpenMP task.  It has to reproduce the clock-level
+    model bit for bit before it is timed.  Best of 5 after one warm-up."""
+    import tempfile
+    import numpy as np
+    import ua3reo_ddc
+    from oracle import oracle
+    L = oracle.build_native_variant(tempfile.mkdtemp(prefix="ddc_oracle_"))
+    samples, distinct, per_thread = 1 << 22, 4, 24
+    rows = np.stack([ua3reo_ddc.pack_adc12(ua3reo_ddc.synth_adc(c, samples)) for c in range(distinct)])
+    rb = rows.shape[1]
+    n_ch = threads * per_thread
+    phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * c)[0] for c in range(n_ch)]
+    a = oracle.rx_chain_packed_mt(L, rows, rb, distinct, distinct, 1 << 17, phis[:distinct], threads)
+    b = oracle.rx_chain_packed(rows, rb, distinct, 1 << 17, phis[:distinct])
+    if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+        raise SystemExit("bench: the vectorised CPU chain disagrees with the clock-level oracle")
+    t0 = time.perf_counter()
+    oracle.rx_chain_packed(rows, rb, 1, samples, phis[:1], L=L)
+    clock_one = samples / (time.perf_counter() - t0) / 1e6
+    best, used = 0.0, threads
+    for rep in range(6):
+        t0 = time.perf_counter()
+        _, _, used = oracle.rx_chain_packed_mt(L, rows, rb, distinct, n_ch, samples, phis, threads)
+        dt = time.perf_counter() - t0
+        if rep:
+            best = max(best, n_ch * samples / dt / 1e6)
+    one = 0.0
+    for rep in range(3):
+        t0 = time.perf_counter()
+        oracle.rx_chain_packed_mt(L, rows, rb, distinct, 8, samples, phis[:8], 1)
+        one = max(one, 8 * samples / (time.perf_counter() - t0) / 1e6)
+    return best, one, used, (
+        "best of 5: %d OpenMP threads x %d channel-passes x %d samples, oracle/ddc_oracle.c window form "
+        "(gcc -O3 -march=native -fopenmp, 16 windows in the vector lanes, bit-exact vs the clock-level model, which runs "
+        "%.0f MS/s on one thread); nproc reports %d CPUs, OMP_NUM_THREADS=%s"
+        % (used, per_thread, samples, clock_one, os.cpu_count() or 0, os.environ.get("OMP_NUM_THREADS", "unset")))
+
+
+def dry_run(args, rank, world):
+    """The multi-rank path without a GPU: gloo ranks, the same StepGather the GPU path uses,
+    a pattern that depends on (rank, step, position) in place of the kernels."""
+    import torch
+    import torch.distributed as dist
+    from ua3reo_ddc import shard
+    with _StdoutToStderr():  # gloo announces its connections on stdout
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    nch, nf = args.channels, max(1, args.samples // 1024)
+    sg = shard.StepGather(dist, (2, nch, nf, 2), torch.int16, "cpu", timed=False)
+
+    def pattern(r, k):
+        base = torch.arange(2 * nch * nf * 2, dtype=torch.int64).reshape(2, nch, nf, 2)
+        return ((base * 7 + 1000 * r + 31 * k) % 30011).to(torch.int16)
+
+    total = args.warmup + args.steps
+    dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(total):
+        sg.buffer(k).copy_(pattern(rank, k))
+        sg.submit(k)
+    sg.finish()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = all(torch.equal(sg.result(k)[r], pattern(r, k)) for k in range(max(0, total - 2), total) for r in range(world))
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": 0.0, "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / max(1, total) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "none", "data": "dry run on CPUs (gloo): a pattern stands in for the kernels",
+            "config": {"workload": "dry run: %d channels x %d frames per rank" % (nch, nf),
+                       "all_gather": {"bytes_per_rank": int(sg.outs[0].numel() * 2), "backend": "gloo",
+                                      "gathered_equals_pattern": bool(ok)}}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_gather:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if args.dry_run_gloo:
+        return dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
+    do_gather = world > 1 or args.force_gather
+    if do_gather:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         # stdout carries the one JSON line: RCCL's own banner / debug text goes to stderr
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         os.environ.setdefault("RANK", "0")
@@ -179,6 +238,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import ua3reo_ddc
+    from ua3reo_ddc import shard
     if args.workload == "tx":
         return bench_tx(args, dev, local_rank, rank, world, dist)
     nch, S = args.channels, args.samples
@@ -187,14 +247,12 @@ def main():
     rb = S // 2 * 3
     chan0 = rank * nch
     shared = args.shared_stream
-    adc = synth_rows(1 if shared else nch, S, chan0, dev, 0x5EED0000 + rank)
+    # synthetic rows: the library's generator (two tones + xorshift64* noise per channel), run on the GPU
+    n_rows = 1 if shared else nch
+    adc = torch.empty((n_rows, rb), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ua3reo_ddc.synth_adc_dev(chan0, n_rows, S, adc.data_ptr(), rb, FS_ADC)
     pitch = 0 if shared else rb
-    # [buffer][SPEC|VOICE][channel][frame][I,Q]; two buffers so that the gather of
-    # step k overlaps the compute of step k+1
-    outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
-    out = outs[0]
-    do_gather = world > 1 or args.force_gather
-    gathered = torch.zeros((world * 2, nch, nf, 2), dtype=torch.int16, device=dev) if do_gather else None
     with_fft = args.workload == "ddc+fft"
     if with_fft:
         assert nf % 512 == 0, "ddc+fft needs samples to be a multiple of 512*1024"
@@ -203,73 +261,85 @@ def main():
     phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * (chan0 + c))[0] for c in range(nch)]
     ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
     ctx.tune_many(phis)
+    fft_params = dict(mode="USB", fft_averaging=4)
     if with_fft:
-        ctx.audio_configure(ua3reo_ddc.audio_params(mode="USB", fft_averaging=4))
+        ctx.audio_configure(ua3reo_ddc.audio_params(**fft_params))
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
-    comm = torch.cuda.Stream(device=dev) if do_gather else None
-    computed = [torch.cuda.Event(), torch.cuda.Event()]
-    gathered_ev = [torch.cuda.Event(), torch.cuda.Event()]
+    # [buffer][SPEC|VOICE][channel][frame][I,Q]; two buffers so that the gather of step k
+    # overlaps the compute of step k+1 (ua3reo_ddc/shard.py, StepGather)
+    if do_gather:
+        sg = shard.StepGather(dist, (2, nch, nf, 2), torch.int16, dev, compute_stream=ext, timed=True)
+        outs = sg.outs
+    else:
+        sg = None
+        outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
     step_no = [0]
-    gather_times = None  # (start, end) events of every all-gather of the timed region
     torch.cuda.synchronize()
 
     def step():
-        b = step_no[0] & 1
+        k = step_no[0]
         step_no[0] += 1
-        o = outs[b]
-        if do_gather and step_no[0] > 2:
-            ext.wait_event(gathered_ev[b])  # the gather that last read this buffer
+        o = sg.buffer(k) if sg else outs[k & 1]
         ctx.rx_process_dev(adc.data_ptr(), pitch, S, o[0].data_ptr(), o[1].data_ptr())
         if with_fft:
             ctx.fft_process_dev(o[0].data_ptr(), nf, fft_bins.data_ptr(), fft_rows.data_ptr())
-        if do_gather:
-            computed[b].record(ext)
-            comm.wait_event(computed[b])
-            with torch.cuda.stream(comm):
-                if gather_times is not None:
-                    t_a, t_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    t_a.record(comm)
-                dist.all_gather_into_tensor(gathered.view(torch.uint8), o.view(torch.uint8))
-                if gather_times is not None:
-                    t_b.record(comm)
-                    gather_times.append((t_a, t_b))
-                gathered_ev[b].record(comm)
+        if sg:
+            sg.submit(k)
 
-    # parity spot check before any timing: first step from power-on state vs the oracle
+    # parity spot check before any timing: first call from power-on state vs the oracle
     check = "skipped"
     if not args.no_check:
         from oracle import oracle
-        ns = min(S, 1 << 16)
+        ns = min(S, 1 << 19) if with_fft else min(S, 1 << 16)
         chk_ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
         chk_ctx.tune_many(phis)
         chk_out = torch.zeros((2, nch, ns // 1024, 2), dtype=torch.int16, device=dev)
         torch.cuda.synchronize()
         chk_ctx.rx_process_dev(adc.data_ptr(), pitch, ns, chk_out[0].data_ptr(), chk_out[1].data_ptr())
+        n_fft = ns // 1024 // 512 if with_fft else 0
+        if n_fft:
+            chk_ctx.audio_configure(ua3reo_ddc.audio_params(**fft_params))
+            chk_bins = torch.zeros((nch, n_fft, 256), dtype=torch.float32, device=dev)
+            chk_rows = torch.zeros((nch, n_fft, 256), dtype=torch.int16, device=dev)
+            torch.cuda.synchronize()
+            chk_ctx.fft_process_dev(chk_out[0].data_ptr(), n_fft * 512, chk_bins.data_ptr(), chk_rows.data_ptr())
         chk_ctx.sync()
         for c in sorted({0, nch // 2, nch - 1}):
             x = ua3reo_ddc.unpack_adc12(adc[0 if shared else c, : ns // 2 * 3].cpu().numpy(), ns)
+            if c == 0 and not np.array_equal(x, ua3reo_ddc.synth_adc(chan0 + (0 if shared else c), ns, FS_ADC)):
+                raise SystemExit("bench: device-generated ADC rows differ from the host generator")
             os_, ov_ = oracle.RxChain(phis[c]).run(x)
             if not (np.array_equal(chk_out[0, c].cpu().numpy(), os_) and
                     np.array_equal(chk_out[1, c].cpu().numpy(), ov_)):
                 raise SystemExit("bench: GPU output differs from the oracle on channel %d" % c)
+            if n_fft:
+                a = oracle.Audio(oracle.audio_params(**fft_params))
+                for f in range(n_fft):
+                    wb, _, _ = a.fft(os_[512 * f:512 * (f + 1)])
+                    if np.abs(chk_bins[c, f].cpu().numpy() - wb).max() > 1e-4 * max(float(wb.max()), 1e-3):
+                        raise SystemExit("bench: panadapter bins differ from the oracle on channel %d" % c)
         chk_ctx.close()
         del chk_out
-        check = "bit-exact vs oracle on 3 channels x %d samples" % ns
+        check = "bit-exact vs oracle on 3 channels x %d samples%s" % (
+            ns, "; %d panadapter rows each within 1e-4 of the frame maximum" % n_fft if n_fft else "")
 
     for _ in range(args.warmup):
         step()
     ctx.sync()
+    if sg:
+        sg.finish()
+        sg.times.clear()
     torch.cuda.synchronize()
     ctx.profile_enable(True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    if do_gather:
-        gather_times = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.sync()
+    if sg:
+        sg.finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -288,6 +358,41 @@ def main():
         value = units / dt / 1e6
         front_avg_ms = front_ms / max(1, ncalls)
         achieved = BYTES_PER_CHANNEL_SAMPLE * nch * S / (front_avg_ms * 1e-3) / 1e9
+        traffic = None if shared else load_profile("traffic.json", nch, S)
+        valu = None if shared else load_profile("valu.json", nch, S)
+        roof = {
+            "bound": "hbm",
+            "kernel": "ddc_rx_front",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": float(traffic["traffic_bytes"]) if traffic else None,
+            "traffic_source": ("%s @ commit %s" % (traffic["source"], traffic.get("commit", "?"))) if traffic else
+                              "no PMC pass on this kernel source and shape in profiles/",
+            "avg_launch_ms": round(front_avg_ms, 4),
+            "rest_of_call_ms": round(tail_ms / max(1, ncalls), 4),
+            "algorithmic_bytes_per_launch": BYTES_PER_CHANNEL_SAMPLE * nch * S,
+        }
+        if valu:
+            # vector-ALU issue roof: instruction counts of the PMC pass priced with the probe's issue
+            # cycles per instruction class, against the SIMD cycles of this run's launches
+            waves = nch * S / 64.0
+            need = (valu["slow_per_sample"] * valu["issue_cycles_slow"] +
+                    valu["fast_per_sample"] * valu["issue_cycles_fast"]) * waves
+            have = N_SIMD * front_avg_ms * 1e-3 * valu["clock_ghz"] * 1e9
+            roof_s = need / (N_SIMD * valu["clock_ghz"] * 1e9)  # launch time if the SIMDs never waited
+            roof["valu"] = {
+                "insts_per_sample": valu["insts_per_sample"],
+                "slow_per_sample": valu["slow_per_sample"], "fast_per_sample": valu["fast_per_sample"],
+                "issue_cycles_per_inst": {"slow": valu["issue_cycles_slow"], "fast": valu["issue_cycles_fast"]},
+                "clock_ghz": valu["clock_ghz"],
+                "issue_util": round(need / have, 4),
+                "launch_ms_at_issue_roof": round(roof_s * 1e3, 4),
+                "hbm_frac_at_issue_roof": round(BYTES_PER_CHANNEL_SAMPLE * nch * S / roof_s / 1e9 / HBM_PEAK_GBS, 4),
+                "source": "%s @ commit %s" % (valu["source"], valu.get("commit", "?")),
+            }
+            roof["closer_roof"] = "valu-issue" if need / have > achieved / HBM_PEAK_GBS else "hbm"
         res = {
             "metric": METRIC,
             "value": round(value, 1),
@@ -300,7 +405,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "i32/i64 integer (12-bit ADC, 60-bit CIC)",
-            "data": "synthetic: two tones + uniform noise per channel, packed 12-bit, generated on device",
+            "data": "synthetic: two tones + xorshift64* noise per channel (seed 0x5EED0000 + channel), packed 12-bit, "
+                    "generated on the device by ddc_synth_adc_dev",
             "config": {
                 "workload": "%s: %d channels x %d ADC samples per step, "
                             "full FPGA RX chain (NCO+mixer+rx_cic+rx_ciccomp+rx_hilb/delay) to SPEC+VOICE int16 I/Q%s"
@@ -312,43 +418,36 @@ def main():
                 "fs_adc_hz": FS_ADC,
                 "parallelism": "channels sharded over %d GPU(s)%s" % (
                     world, ", RCCL all-gather of decimated I/Q each step, overlapped with the next step"
-                    if world > 1 else ""),
+                    if do_gather else ""),
                 "parity_check": check,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "ddc_rx_front",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None if shared else measured_traffic(nch, S),
-                "avg_launch_ms": round(front_avg_ms, 4),
-                "rest_of_call_ms": round(tail_ms / max(1, ncalls), 4),
-                "algorithmic_bytes_per_launch": BYTES_PER_CHANNEL_SAMPLE * nch * S,
-            },
+            "roofline": roof,
         }
-        if gather_times:
-            g_ms = sum(a.elapsed_time(b) for a, b in gather_times) / len(gather_times)
+        if sg and sg.times:
+            g_ms = sg.average_ms()
             res["config"]["all_gather"] = {"avg_ms": round(g_ms, 4), "bytes_per_rank": int(outs[0].numel() * 2),
                                            "share_of_step": round(g_ms / (dt / args.steps * 1e3), 4),
                                            "note": "on a second stream, overlapped with the next step's compute"}
         if not args.no_cpu_baseline and world == 1:
-            threads = min(16, os.cpu_count() or 1)
-            v, one, sample = cpu_baseline(threads)
-            res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": threads,
+            want = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1)
+            threads = max(1, min(want, os.cpu_count() or 1))
+            v, one, used, sample = cpu_baseline(threads)
+            res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": used,
                                    "kind": "port", "sample": sample, "one_thread": round(one, 1)}
         print(json.dumps(res), flush=True)
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def bench_tx(args, dev, local_rank, rank, world, dist):
     """DUC: 48 kHz I/Q -> tx_ciccomp x2 -> tx_cic x512 -> mixer -> 14-bit DAC words.
     One step = args.samples DAC samples per channel; HBM traffic is the 2-byte DAC
     word written per sample plus 4 bytes read per 1024."""
+    import numpy as np
+    import torch
     import ua3reo_ddc
     nch, S = args.channels, args.samples
     assert S % 1024 == 0
@@ -426,7 +525,8 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

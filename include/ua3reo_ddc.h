@@ -332,6 +332,12 @@ int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes);
 void ddc_pack_adc12(const int16_t *samples, size_t n, uint8_t *packed);
 void ddc_unpack_adc12(const uint8_t *packed, size_t n, int16_t *samples);
 void ddc_synth_adc(uint32_t channel, uint32_t fs_adc, size_t n, int16_t *samples);
+/* The same signal generated on the GPU, packed: rows[c] (device memory of the current
+ * device, rows row_bytes apart) receives ddc_pack_adc12(ddc_synth_adc(first_channel + c))
+ * for c < n_channels; samples a multiple of 512.  Allocates a small scratch buffer and
+ * waits for hip_stream (a hipStream_t, NULL = the default stream).  Bench / test helper. */
+int ddc_synth_adc_dev(uint32_t first_channel, uint32_t n_channels, uint32_t fs_adc, size_t samples, uint8_t *rows,
+                      size_t row_bytes, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -171,7 +171,7 @@ def build_native_variant(out_dir):
     timing the CPU baseline; returns a CDLL of its own, ready to use."""
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libddc_oracle_native.so")
-    subprocess.check_call(["gcc", "-O3", "-march=native", "-mprefer-vector-width=512", "-fPIC", "-std=c11",
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-mprefer-vector-width=512", "-fopenmp", "-fPIC", "-std=c11",
                            "-ffp-contract=off", "-shared", "-o", so,
                            os.path.join(_HERE, "ddc_oracle.c"), os.path.join(_HERE, "audio_oracle.c"), "-lm"])
     L = C.CDLL(so)
@@ -191,6 +191,20 @@ def rx_chain_packed(packed, row_bytes, n_channels, n, phi, L=None, fast=False):
     f = (L or lib()).orc_fast_rx_chain_packed if fast else (L or lib()).orc_rx_chain_packed
     f(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_channels), C.c_size_t(n), _p(phi), _p(spec), _p(voice))
     return spec, voice
+
+
+def rx_chain_packed_mt(L, packed, row_bytes, n_rows, n_channels, n, phi, threads=0):
+    """orc_fast_rx_chain_packed_mt of a build_native_variant() library: the window-form RX chain
+    over OpenMP threads, channel ch reading row ch % n_rows.  Returns spec, voice, threads used."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    phi = np.ascontiguousarray(phi, dtype=np.uint32)
+    nf = n // 1024
+    spec = np.zeros((n_channels, nf, 2), np.int16)
+    voice = np.zeros((n_channels, nf, 2), np.int16)
+    L.orc_fast_rx_chain_packed_mt.restype = C.c_int
+    used = L.orc_fast_rx_chain_packed_mt(_p(packed), C.c_size_t(row_bytes), C.c_size_t(n_rows), C.c_size_t(n_channels),
+                                         C.c_size_t(n), _p(phi), _p(spec), _p(voice), C.c_int(threads))
+    return spec, voice, used
 
 
 def pack12(x):

@@ -448,3 +448,22 @@ def test_set_params_direction_flip_resets_the_entered_direction(ddc, orc):
     ws0, wv0 = orc.RxChain(phi).run(np.concatenate([adc[0], adc[0][:samples]]))
     assert np.array_equal(s2[0], ws0[2 * samples // 1024:]) and np.array_equal(v2[0], wv0[2 * samples // 1024:])
     d.close()
+
+
+def test_device_synth_rows_equal_the_host_generator(ddc):
+    """ddc_synth_adc_dev fills packed rows on the GPU with the very words
+    ddc_pack_adc12(ddc_synth_adc(channel)) gives on the host (xorshift64* noise, two
+    tones in double precision), for a channel offset and a padded row pitch."""
+    torch = pytest.importorskip("torch")
+    first, n_ch, samples = 1021, 5, 1 << 16
+    rb = samples // 2 * 3 + 256
+    rows = torch.zeros((n_ch, rb), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ddc.synth_adc_dev(first, n_ch, samples, rows.data_ptr(), rb)
+    got = rows.cpu().numpy()
+    for c in range(n_ch):
+        want = ddc.pack_adc12(ddc.synth_adc(first + c, samples))
+        assert np.array_equal(got[c, :samples // 2 * 3], want), c
+        assert not got[c, samples // 2 * 3:].any()
+    with pytest.raises(ddc.DdcError):
+        ddc.synth_adc_dev(0, 1, 1000, rows.data_ptr(), rb)

@@ -246,6 +246,53 @@ __global__ void ddc_rx_save_history(unsigned long long *hm, int16_t *hc, int16_t
             reinterpret_cast<const uint32_t *>(comp)[(size_t)ch * (kCompHist + nf) + nf + t];
     if (t == 0) acc0[ch] += samples_lo * phi32v[ch];
 }
+
+// The synthetic bench signal of ddc_synth_adc on the device.  The noise generator
+// (xorshift64*) is a serial recurrence per channel: pass 1 walks it once per channel
+// and keeps the state at the start of every 512-sample segment, pass 2 fills the
+// segments in parallel (tones in double precision, as the host version).
+constexpr uint32_t kSynthSeg = 512;
+
+__global__ void ddc_synth_states(uint32_t first_channel, uint32_t n_channels, uint32_t n_seg, uint64_t *states)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) return;
+    uint64_t s = 0x5EED0000ull + first_channel + c;
+    for (uint32_t g = 0; g < n_seg; g++) {
+        states[(size_t)c * n_seg + g] = s;
+        for (uint32_t i = 0; i < kSynthSeg; i++) { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; }
+    }
+}
+
+__global__ void ddc_synth_rows(uint32_t first_channel, uint32_t n_channels, uint32_t n_seg, double fs_adc,
+                               const uint64_t *__restrict__ states, uint8_t *__restrict__ rows, size_t row_bytes)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_channels * n_seg) return;
+    const uint32_t c = (uint32_t)(gid / n_seg), g = (uint32_t)(gid - (uint64_t)c * n_seg);
+    uint64_t s = states[gid];
+    const double two_pi = 6.283185307179586476925286766559;
+    const double f1 = 1.0e6 + 48.0e3 * (double)(first_channel + c), f2 = f1 + 1.0e3;
+    const double w1 = two_pi * f1 / fs_adc, w2 = two_pi * f2 / fs_adc;
+    uint8_t *out = rows + (size_t)c * row_bytes + (size_t)g * (kSynthSeg / 2 * 3);
+    int pair[2];
+    for (uint32_t i = 0; i < kSynthSeg; i++) {
+        s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+        const uint64_t r = s * 0x2545F4914F6CDD1Dull;
+        const int noise = (int)(r >> 57) - 64;
+        const double t = (double)((uint64_t)g * kSynthSeg + i);
+        long v = lround(1400.0 * sin(w1 * t) + 300.0 * sin(w2 * t)) + noise;
+        v = v > 2047 ? 2047 : (v < -2047 ? -2047 : v);
+        pair[i & 1] = (int)v;
+        if (i & 1) {
+            const unsigned s0 = (unsigned)pair[0] & 0xFFF, s1 = (unsigned)pair[1] & 0xFFF;
+            uint8_t *b = out + (i / 2) * 3;
+            b[0] = (uint8_t)(s0 & 0xFF);
+            b[1] = (uint8_t)((s0 >> 8) | ((s1 & 0xF) << 4));
+            b[2] = (uint8_t)(s1 >> 4);
+        }
+    }
+}
 } // namespace ddc
 
 extern "C" {
@@ -1557,6 +1604,31 @@ void ddc_synth_adc(uint32_t channel, uint32_t fs_adc, size_t n, int16_t *samples
         if (v < -2047) v = -2047;
         samples[i] = (int16_t)v;
     }
+}
+
+
+int ddc_synth_adc_dev(uint32_t first_channel, uint32_t n_channels, uint32_t fs_adc, size_t samples, uint8_t *rows,
+                      size_t row_bytes, void *hip_stream)
+{
+    if (!rows || n_channels == 0) return fail(nullptr, -EINVAL, "null buffer");
+    if (samples == 0 || samples % ddc::kSynthSeg) return fail(nullptr, -EINVAL, "samples must be a multiple of 512");
+    if (row_bytes < samples / 2 * 3) return fail(nullptr, -EINVAL, "row_bytes smaller than one row of samples");
+    if (samples / ddc::kSynthSeg > 0xFFFFFFFFull || (unsigned long long)n_channels * (samples / ddc::kSynthSeg) >= (1ull << 40))
+        return fail(nullptr, -EINVAL, "too many samples");
+    if (fs_adc == 0) fs_adc = DDC_ADC_CLOCK_DEFAULT;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint32_t n_seg = (uint32_t)(samples / ddc::kSynthSeg);
+    uint64_t *states = nullptr;
+    HIP_TRY(nullptr, hipMalloc(&states, (size_t)n_channels * n_seg * sizeof(uint64_t)));
+    ddc::ddc_synth_states<<<(n_channels + 63) / 64, 64, 0, st>>>(first_channel, n_channels, n_seg, states);
+    const uint64_t items = (uint64_t)n_channels * n_seg;
+    ddc::ddc_synth_rows<<<(uint32_t)((items + 255) / 256), 256, 0, st>>>(first_channel, n_channels, n_seg, (double)fs_adc,
+                                                                       states, rows, row_bytes);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(states);
+    if (e != hipSuccess) return fail(nullptr, -EIO, std::string("ddc_synth_adc_dev: ") + hipGetErrorString(e));
+    return 0;
 }
 
 } /* extern "C" */

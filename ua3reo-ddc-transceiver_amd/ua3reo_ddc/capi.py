@@ -100,6 +100,7 @@ def lib():
     L.ddc_set_params.argtypes = [vp, i32, vp]
     L.ddc_pack_adc12.argtypes = [vp, sz, vp]
     L.ddc_debug_table.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
+    L.ddc_synth_adc_dev.argtypes = [u32, u32, u32, sz, vp, sz, vp]
     L.ddc_pack_adc12.restype = None
     L.ddc_unpack_adc12.argtypes = [vp, sz, vp]
     L.ddc_unpack_adc12.restype = None
@@ -169,6 +170,14 @@ def audio_params(mode="USB", agc=1, dnr=0, notch=0, mute=0, cw_decoder=0, fm_sql
     m = MODES[mode] if isinstance(mode, str) else int(mode)
     return AudioParams(m, agc, dnr, notch, mute, cw_decoder, fm_sql_threshold, volume, iq_swap, fft_averaging,
                        fft_zoom, rf_power, tune, key, 0, 0, filter_width, hpf_pass, notch_fc, agc_speed, rf_gain)
+
+
+def synth_adc_dev(first_channel, n_channels, samples, rows_ptr, row_bytes, fs_adc=0, stream=None):
+    """Packed synthetic ADC rows generated on the GPU into device memory at rows_ptr."""
+    L = lib()
+    rc = L.ddc_synth_adc_dev(first_channel, n_channels, fs_adc, samples, rows_ptr, row_bytes, stream)
+    if rc != 0:
+        raise DdcError("error %d: %s" % (rc, L.ddc_last_error(None).decode()))
 
 
 def debug_table(name, dtype):
