@@ -380,7 +380,10 @@ def main(argv=None):
             waves = nch * S / 64.0
             need = (valu["slow_per_sample"] * valu["issue_cycles_slow"] +
                     valu["fast_per_sample"] * valu["issue_cycles_fast"]) * waves
-            have = N_SIMD * front_avg_ms * 1e-3 * valu["clock_ghz"] * 1e9
+            # SIMD cycles of one launch: counted in the PMC pass (GRBM_GUI_ACTIVE is summed over the 8 XCDs),
+            # which does not depend on the clock the chip held; else this run's time at the probed clock
+            have = N_SIMD * (valu["grbm_gui_active"] / 8.0 if valu.get("grbm_gui_active") else
+                             front_avg_ms * 1e-3 * valu["clock_ghz"] * 1e9)
             roof_s = need / (N_SIMD * valu["clock_ghz"] * 1e9)  # launch time if the SIMDs never waited
             roof["valu"] = {
                 "insts_per_sample": valu["insts_per_sample"],

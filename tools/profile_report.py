@@ -9,7 +9,7 @@ d = "gpurun_out/" + tag
 rows = list(csv.DictReader(open(d + "/kernel_stats.csv")))
 out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (MI355X; default workload: 1024 channels x "
        "2^20 samples, 3 warm-up + 20 timed steps + 1 parity-check call of 65536 samples)",
-       "# library kernels only; the rest of the trace is torch generating the synthetic ADC rows before the timed region",
+       "# library kernels only (ddc_synth_* generate the synthetic ADC rows before the timed region)",
        "%-28s %6s %14s %12s %10s %10s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns")]
 for r in rows:
     n = r["Name"].split("(")[0]
