@@ -350,6 +350,14 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     {
+        // compensator taps as the kernel multiplies them: pair m covers samples 2n - 64 + 2m, + 1
+        uint32_t cp[33];
+        for (int m = 0; m < 32; m++)
+            cp[m] = (uint32_t)(uint16_t)rx_ciccomp_h[64 - 2 * m] | ((uint32_t)(uint16_t)rx_ciccomp_h[63 - 2 * m] << 16);
+        cp[32] = (uint32_t)(uint16_t)rx_ciccomp_h[0];
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_ciccomp_pairs), cp, sizeof cp));
+    }
+    {
         // Hilbert taps as the kernel wants them: reversed pairs and the two low bit planes
         uint32_t pairs[128], odd[8] = {0}, bit1[8] = {0};
         for (int m = 0; m < 128; m++)
@@ -360,6 +368,9 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
             bit1[j >> 5] |= ((c >> 1) & 1u) << (j & 31);
         }
         CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs), pairs, sizeof pairs));
+        uint32_t padded[144] = {0};
+        memcpy(padded + 3, pairs, sizeof pairs);
+        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs_pad), padded, sizeof padded));
         CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_odd), odd, sizeof odd));
         CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_bit1), bit1, sizeof bit1));
     }
@@ -562,9 +573,8 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
     const uint32_t ctiles = (n_blk + 255) / 256;
     ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(mom, n_blk, ctiles, cic);
-    const uint32_t nfr = nch * nf;
-    ddc::ddc_rx_ciccomp<<<(nfr + 255) / 256, 256, 0, st>>>(cic, n_blk, nch, comp, spec_iq);
-    const uint32_t tiles = (nf + 255) / 256;
+    const uint32_t tiles = (nf + ddc::kTailTile - 1) / ddc::kTailTile;
+    ddc::ddc_rx_ciccomp<<<nch * tiles, 256, 0, st>>>(cic, n_blk, tiles, comp, spec_iq);
     ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(comp, nf, tiles, voice_iq);
     ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, mom, cic, comp,
                                                  ctx->d_acc, ctx->d_phi, n_blk, (uint32_t)samples);

@@ -618,33 +618,78 @@ __device__ __forceinline__ int cround32(uint32_t v, int s, int bits)
 
 __constant__ int16_t c_rx_ciccomp_h[65];
 __constant__ int16_t c_rx_hilb_c[256];
+// rx_ciccomp taps as the kernel multiplies them: pair m = {h[64-2m] | h[63-2m] << 16}, m = 0..31, and {h[0] | 0}
+__constant__ uint32_t c_ciccomp_pairs[33];
+
+constexpr int kTailTile = 1024; // outputs per workgroup of the two 48 kHz kernels (256 threads x 4)
 
 /*
  * Kernel 3.  rx_ciccomp: e[n] = wrap16(cround(sum_{i=0..64} h[i] * c[2n-i], 15))
- * for I and Q (FPGA/rx_ciccomp.vhd:616; only the low 31 bits of the sum matter).
- * Writes SPEC I/Q to the caller and to comp: [channel][kCompHist + nf][2].
+ * for I and Q (FPGA/rx_ciccomp.vhd:616; only the low 31 bits of the sum matter,
+ * so the sums run mod 2^32).  Writes SPEC I/Q to the caller and to
+ * comp: [channel][kCompHist + nf][2].
+ *
+ * A workgroup computes 1024 consecutive outputs of one channel.  The 2112 rx_cic
+ * samples they reach are split into an I and a Q array of int16 in LDS, so that a
+ * dword holds two consecutive samples of one branch and one v_dot2 does two taps;
+ * a thread computes four consecutive outputs from a sliding window of 36 pairs
+ * (nine 16-byte LDS reads per branch, contiguous across the lanes).
  */
-__global__ void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, uint32_t n_ch,
-                               int16_t *__restrict__ comp, int16_t *__restrict__ spec_iq)
+__global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, uint32_t tiles,
+                                                     int16_t *__restrict__ comp, int16_t *__restrict__ spec_iq)
 {
+    constexpr int kIn = 2 * kTailTile + 64;          // samples staged per branch: 2 n0 - 64 .. 2 n0 + 2047
+    __shared__ __align__(16) int16_t si[kIn + 8], sq[kIn + 8];
     const uint32_t nf = n_blk / 2;
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_ch * nf) return;
-    const uint32_t ch = (uint32_t)(gid / nf), n = (uint32_t)(gid - (uint64_t)ch * nf);
-    const uint32_t *x = reinterpret_cast<const uint32_t *>(cic) +
-                        ((size_t)ch * (kCicHist + n_blk) + kCicHist + 2 * (size_t)n);
-    uint32_t ai = 0, aq = 0;
-#pragma unroll 13
-    for (int i = 0; i < 65; i++) {
-        const uint32_t v = x[-i];
-        const int h = c_rx_ciccomp_h[i];
-        ai += (uint32_t)(h * (int)(int16_t)(v & 0xFFFFu));
-        aq += (uint32_t)(h * ((int)v >> 16));
+    const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * (uint32_t)kTailTile, t = threadIdx.x;
+    // staged sample j is entry kCicHist + 2 n0 - 64 + j of the channel (kCicHist = 64: entry 2 n0 + j)
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(cic) + (size_t)ch * (kCicHist + n_blk);
+    const uint32_t last = kCicHist + n_blk - 1;
+    for (uint32_t j = t; j < (uint32_t)kIn + 8; j += 256) {
+        uint32_t e = 2 * n0 + j;
+        e = e < last ? e : last;
+        const uint32_t v = x[e];
+        si[j] = (int16_t)(v & 0xFFFFu);
+        sq[j] = (int16_t)(v >> 16);
     }
-    const int16_t ei = (int16_t)cround32(ai, 15, 31), eq = (int16_t)cround32(aq, 15, 31);
-    const uint32_t packed = (uint32_t)(uint16_t)ei | ((uint32_t)(uint16_t)eq << 16);
-    reinterpret_cast<uint32_t *>(comp)[(size_t)ch * (kCompHist + nf) + kCompHist + n] = packed;
-    reinterpret_cast<uint32_t *>(spec_iq)[(size_t)ch * nf + n] = packed;
+    __syncthreads();
+    // outputs n0 + 4 t + k, k = 0..3: output k uses pairs (4 t + k) + m, m = 0..32, of the staged arrays
+    const uint4 *pi = reinterpret_cast<const uint4 *>(si) + t, *pq = reinterpret_cast<const uint4 *>(sq) + t;
+    int ai[4] = {0, 0, 0, 0}, aq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const uint4 vi = pi[q], vq = pq[q];
+        const uint32_t wi[4] = { vi.x, vi.y, vi.z, vi.w }, wq[4] = { vq.x, vq.y, vq.z, vq.w };
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int m = 4 * q + e - k;
+                if (m >= 0 && m < 33) {
+                    ai[k] = dot2(wi[e], c_ciccomp_pairs[m], ai[k]);
+                    aq[k] = dot2(wq[e], c_ciccomp_pairs[m], aq[k]);
+                }
+            }
+        }
+    }
+    const uint32_t n = n0 + 4 * t;
+    if (n >= nf) return;
+    uint32_t packed[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int16_t ei = (int16_t)cround32((uint32_t)ai[k], 15, 31), eq = (int16_t)cround32((uint32_t)aq[k], 15, 31);
+        packed[k] = (uint32_t)(uint16_t)ei | ((uint32_t)(uint16_t)eq << 16);
+    }
+    uint32_t *oc = reinterpret_cast<uint32_t *>(comp) + (size_t)ch * (kCompHist + nf) + kCompHist + n;
+    uint32_t *os = reinterpret_cast<uint32_t *>(spec_iq) + (size_t)ch * nf + n;
+    if (n + 3 < nf && (nf & 3u) == 0 && ((uintptr_t)os & 15u) == 0) { // whole quad, 16-byte aligned rows
+        *reinterpret_cast<uint4 *>(oc) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        *reinterpret_cast<uint4 *>(os) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (n + k < nf) { oc[k] = packed[k]; os[k] = packed[k]; }
+    }
 }
 
 /*
@@ -660,26 +705,32 @@ __global__ void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, 
  * the taps' as constant masks they are population counts, 8 dwords per output.
  * Only the low 30 bits of the sum matter, so everything runs mod 2^32.
  *
- * A workgroup computes 256 consecutive outputs of one channel from the 511
+ * A workgroup computes 1024 consecutive outputs of one channel from the 1279
  * samples they reach, staged in LDS twice (the second copy one sample on, so
- * that odd outputs also read aligned pairs) plus the two bit planes.
+ * that odd outputs also read aligned pairs) plus the two bit planes.  A thread
+ * computes four outputs of one parity, two samples apart, from a sliding window
+ * of 131 pairs (33 16-byte LDS reads, contiguous across the lanes): waves 0-1
+ * take the even outputs, waves 2-3 the odd ones.
  */
 __constant__ uint32_t c_hilb_pairs[128]; // {c[255-2m] | c[254-2m] << 16}
+__constant__ uint32_t c_hilb_pairs_pad[144]; // the same at [3 + m], zeros around: the sliding window needs no bounds
 __constant__ uint32_t c_hilb_odd[8];     // bit j of the 256-bit mask: c[255-j] & 1
 __constant__ uint32_t c_hilb_bit1[8];    // bit j: (c[255-j] >> 1) & 1
 
 __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict__ comp, uint32_t nf, uint32_t tiles,
                                                      int16_t *__restrict__ voice_iq)
 {
-    __shared__ uint32_t xa[256], xb[256];
-    __shared__ uint32_t p0[17], p1[17];
-    const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * 256u, t = threadIdx.x;
+    constexpr int kIn = kTailTile + 256;             // 1280 staged samples (1279 used)
+    __shared__ __align__(16) uint32_t xs[2][kIn / 2]; // [0]: pairs (2m, 2m+1), [1]: pairs (2m+1, 2m+2)
+    __shared__ uint32_t p0[kIn / 32 + 2], p1[kIn / 32 + 2];
+    uint32_t *xa = xs[0], *xb = xs[1];
+    const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * (uint32_t)kTailTile, t = threadIdx.x;
     const uint32_t *x = reinterpret_cast<const uint32_t *>(comp) + (size_t)ch * (kCompHist + nf);
     const uint32_t last = kCompHist + nf - 1;
     int16_t *sa = reinterpret_cast<int16_t *>(xa), *sb = reinterpret_cast<int16_t *>(xb);
     // tile sample j is entry n0 + 1 + j of the channel (sample n0 - 255 + j)
 #pragma unroll
-    for (uint32_t j = t; j < 512; j += 256) {
+    for (uint32_t j = t; j < (uint32_t)kIn; j += 256) {
         uint32_t e = n0 + 1 + j;
         e = e < last ? e : last;
         const int v = (int)(int16_t)(x[e] & 0xFFFFu);
@@ -692,29 +743,47 @@ __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict_
             p1[w] = (uint32_t)b1; p1[w + 1] = (uint32_t)(b1 >> 32);
         }
     }
-    if (t == 0) { p0[16] = 0; p1[16] = 0; sb[511] = 0; }
+    if (t == 0) { p0[kIn / 32] = 0; p0[kIn / 32 + 1] = 0; p1[kIn / 32] = 0; p1[kIn / 32 + 1] = 0; sb[kIn - 1] = 0; }
     __syncthreads();
-    const uint32_t n = n0 + t;
-    if (n >= nf) return;
-    const uint32_t *src = ((t & 1u) ? xb : xa) + (t >> 1);
-    int S = 0;
+    // thread (par, g): outputs o_k = 8 g + par + 2 k, k = 0..3; output k uses pairs (4 g + k) + m, m = 0..127
+    const uint32_t par = t >> 7, g = t & 127u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(&xs[0][0]) + par * (kIn / 8) + g;
+    int S[4] = {0, 0, 0, 0};
+    // quad q holds pairs 4 q + e; output k multiplies pair j with tap pair j - k, i.e. taps
+    // 4 q - 3 .. 4 q + 3 (zero outside 0..127): seven scalar loads per quad
+#pragma unroll 3
+    for (int q = 0; q < 33; q++) {
+        const uint4 v = src[q];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        uint32_t c[7];
 #pragma unroll
-    for (int m = 0; m < 128; m++) S = dot2(src[m], c_hilb_pairs[m], S);
-    const uint32_t w0 = t >> 5, sh = t & 31u;
-    uint32_t n1 = 0, n3 = 0;
+        for (int i = 0; i < 7; i++) c[i] = c_hilb_pairs_pad[4 * q + i];
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-        const uint32_t a0 = __builtin_amdgcn_alignbit(p0[w0 + d + 1], p0[w0 + d], sh);
-        const uint32_t a1 = __builtin_amdgcn_alignbit(p1[w0 + d + 1], p1[w0 + d], sh);
-        const uint32_t both = a0 & c_hilb_odd[d];
-        n1 += __popc(both);
-        n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) S[k] = dot2(w[e], c[3 + e - k], S[k]);
+        }
     }
-    const uint32_t acc = (((uint32_t)S - n1) >> 1) + n3;
-    const int16_t vi = (int16_t)cround32(acc, 14, 30);
-    const int16_t vq = (int16_t)((int)x[kCompHist + n - 130] >> 16);
-    reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
-        (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
+        if (n >= nf) continue;
+        const uint32_t w0 = o >> 5, sh = o & 31u;
+        uint32_t n1 = 0, n3 = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const uint32_t a0 = __builtin_amdgcn_alignbit(p0[w0 + d + 1], p0[w0 + d], sh);
+            const uint32_t a1 = __builtin_amdgcn_alignbit(p1[w0 + d + 1], p1[w0 + d], sh);
+            const uint32_t both = a0 & c_hilb_odd[d];
+            n1 += __popc(both);
+            n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
+        }
+        const uint32_t acc = (((uint32_t)S[k] - n1) >> 1) + n3;
+        const int16_t vi = (int16_t)cround32(acc, 14, 30);
+        const int16_t vq = (int16_t)((int)x[kCompHist + n - 130] >> 16);
+        reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
+            (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
+    }
 }
 
 } // namespace ddc
