@@ -467,3 +467,28 @@ def test_device_synth_rows_equal_the_host_generator(ddc):
         assert not got[c, samples // 2 * 3:].any()
     with pytest.raises(ddc.DdcError):
         ddc.synth_adc_dev(0, 1, 1000, rows.data_ptr(), rb)
+
+
+@pytest.mark.parametrize("frames,parts", [(1500, (1500,)), (2049, (1030, 1019)), (1027, (5, 1022))])
+def test_48k_kernels_across_tile_boundaries(ddc, orc, frames, parts):
+    """The compensator and Hilbert kernels work in tiles of 1024 outputs, four per thread:
+    frame counts that end inside a tile, one past a tile, not a multiple of four, and calls
+    split at odd places must all give the oracle's stream."""
+    n_ch = 3
+    rng = np.random.default_rng(frames)
+    adc = rng.integers(-2048, 2048, size=(n_ch, 1024 * frames)).astype(np.int16)
+    phis = [605867, 1 << 20, 4194303]
+    d = ddc.Ddc(n_ch)
+    d.tune_many(phis)
+    spec, voice, at = [], [], 0
+    for p in parts:
+        rows = np.stack([ddc.pack_adc12(adc[c, 1024 * at:1024 * (at + p)]) for c in range(n_ch)])
+        s, v = d.rx_process(rows, 1024 * p)
+        spec.append(s)
+        voice.append(v)
+        at += p
+    d.close()
+    spec, voice = np.concatenate(spec, axis=1), np.concatenate(voice, axis=1)
+    for c in range(n_ch):
+        ws, wv = orc.RxChain(phis[c]).run(adc[c])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c

@@ -7,6 +7,6 @@ for n in "$@"; do
     python3 - gpurun_out/$tag/$n.json $n <<'PY'
 import json, sys
 r = json.load(open(sys.argv[1]))
-print("%-16s value %9.0f MS/s  step %.4f ms  front %.4f ms  frac %.4f  rest %.4f  check: %s" % (sys.argv[2], r["value"], r["ms_per_step"], r["roofline"]["avg_launch_ms"], r["roofline"]["frac"], r["roofline"]["rest_of_call_ms"], r["config"]["parity_check"][:20]))
+print("%-16s value %9.0f MS/s  step %.4f ms  kernel %.4f ms  frac %.4f  rest %.4f  check: %s" % (sys.argv[2], r["value"], r["ms_per_step"], r["roofline"]["avg_launch_ms"], r["roofline"]["frac"], r["roofline"].get("rest_of_call_ms", 0.0), r["config"]["parity_check"][:20]))
 PY
 done
