@@ -427,3 +427,40 @@ def test_config3_chain_256_channels_ddc_into_panadapter(ddc, orc):
             assert np.abs(b1[c, f] - wb).max() <= 1e-4 * max(float(wb.max()), 1e-3), (c, f)
             bad_pixels += int((r1[c, f] != wr).sum())
     assert bad_pixels <= 4
+
+
+def test_config2_one_channel_one_second_to_audio(ddc, orc):
+    """BASELINE config 2 at its shape: one channel, one second of a 65 MS/s converter
+    (347 x 192 x 1024 = 68.2 M samples) through NCO + CIC + compensator + Hilbert and the
+    USB demodulator (2.7 kHz LPF, 300 Hz HPF, AGC on, DNR off) to 66624 audio frames at
+    65 MHz / 1024.  SPEC / VOICE and the audio frames are compared with the oracle bit for
+    bit over the whole second; the GPU side runs on device buffers."""
+    torch = pytest.importorskip("torch")
+    fs = 65000000
+    samples = 347 * 192 * 1024
+    nf = samples // 1024
+    rb = samples // 2 * 3
+    d = ddc.Ddc(1, fs_adc=fs)
+    phi = orc.phrase_from_freq(1000000, fs)[0]
+    assert not d.tune_hz(0, 1000000)             # first Nyquist zone: no I/Q swap
+    assert ddc.phrase_from_frequency(1000000, fs)[0] == phi
+    params = dict(mode="USB", filter_width=2700, hpf_pass=300, agc=1, dnr=0)
+    d.audio_configure(ddc.audio_params(**params))
+    adc = torch.empty((1, rb), dtype=torch.uint8, device="cuda")
+    spec = torch.zeros((1, nf, 2), dtype=torch.int16, device="cuda")
+    voice = torch.zeros_like(spec)
+    audio = torch.zeros((1, nf, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ddc.synth_adc_dev(0, 1, samples, adc.data_ptr(), rb, fs)
+    d.rx_process_dev(adc.data_ptr(), rb, samples, spec.data_ptr(), voice.data_ptr())
+    d.audio_rx_process_dev(spec.data_ptr(), voice.data_ptr(), nf, audio.data_ptr())
+    d.sync()
+    x = ddc.unpack_adc12(adc[0].cpu().numpy(), samples)
+    assert np.array_equal(x[:4096], ddc.synth_adc(0, 4096, fs))
+    ws, wv = orc.RxChain(phi).run(x)
+    assert np.array_equal(spec[0].cpu().numpy(), ws) and np.array_equal(voice[0].cpu().numpy(), wv)
+    want = orc.Audio(orc.audio_params(**params)).rx(ws, wv)
+    got = audio[0].cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.abs(got[nf // 2:]).max() > 1000      # the 1 kHz beat of the two tones is in the passband
+    d.close()

@@ -11,16 +11,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ua3reo-ddc-transceiver_amd"))
 import torch  # noqa: E402
 import ua3reo_ddc as u  # noqa: E402
-from bench import synth_rows  # noqa: E402
 
 S = 347 * 192 * 1024  # 68.2 M samples: a whole number of 192-frame audio blocks
 dev = torch.device("cuda", 0)
-adc = synth_rows(1, S, 0, dev, 0x5EED0000)
+adc = torch.empty((1, S // 2 * 3), dtype=torch.uint8, device=dev)
+torch.cuda.synchronize()
+u.synth_adc_dev(0, 1, S, adc.data_ptr(), S // 2 * 3, 65000000)
 nf = S // 1024
 spec = torch.zeros((1, nf, 2), dtype=torch.int16, device=dev)
 voice = torch.zeros_like(spec)
 audio = torch.zeros((1, nf, 2), dtype=torch.int32, device=dev)
-d = u.Ddc(1)
+d = u.Ddc(1, fs_adc=65000000)
 d.tune_hz(0, 1000000)
 d.audio_configure(u.audio_params(mode="USB", filter_width=2700, hpf_pass=300, agc=1, dnr=0))
 torch.cuda.synchronize()
