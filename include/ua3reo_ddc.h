@@ -97,7 +97,11 @@ int ddc_rx_process(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t 
  * Every ctx on a GPU shares that GPU's area: calls of this entry point that
  * overlap in time on one GPU (two ctxs on two streams) race; calls on one stream,
  * or ordered by the caller, do not.  Mixing it with ddc_rx_process_dev on the
- * same ctx is fine: the carried state lives in the ctx, not in the area. */
+ * same ctx is fine: the carried state lives in the ctx, not in the area.
+ * Every piece of carried state (NCO phase, mixer carries, filter histories) is
+ * advanced by the kernels on the device, none by the host: one call captured in a
+ * HIP graph on the stream given to ddc_set_stream can be replayed for chunk after
+ * chunk of the same shape, with fresh input written into the same buffers. */
 int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
                               int16_t *spec_iq, int16_t *voice_iq);
 size_t ddc_rx_static_scratch_bytes(void);

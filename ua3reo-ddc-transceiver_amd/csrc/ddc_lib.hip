@@ -27,8 +27,7 @@ struct ddc_ctx {
     // device state, per channel
     uint32_t *d_acc = nullptr;   // NCO phase << 10
     uint32_t *d_phi = nullptr;   // tuning word << 10
-    uint32_t *d_carry[2] = {nullptr, nullptr};
-    int carry_sel = 0;
+    uint32_t *d_carry[2] = {nullptr, nullptr}; // [0] saved between calls, [1] the copy one call reads
     uint2 *d_nco_tab = nullptr;
     // work buffers, sized for cap_blk blocks of 512 samples per channel
     uint32_t cap_blk = 0;
@@ -219,9 +218,13 @@ namespace ddc {
 // history <-> work buffer moves: the work buffers are laid out for the block
 // count of the current call, the saved history is not.
 __global__ void ddc_rx_load_history(const unsigned long long *hm, const int16_t *hc, const int16_t *he,
-                                    unsigned long long *mom, int16_t *cic, int16_t *comp, uint32_t n_blk)
+                                    unsigned long long *mom, int16_t *cic, int16_t *comp, uint32_t n_blk,
+                                    const uint32_t *carry_saved, uint32_t *carry_work)
 {
     const uint32_t ch = blockIdx.x, t = threadIdx.x, nf = n_blk / 2;
+    // the ingest kernel reads the previous call's carries from the copy while its
+    // last block of the channel overwrites the saved ones
+    if (t < 6) carry_work[ch * 6 + t] = carry_saved[ch * 6 + t];
     if (t < kMomHist * 10) mom[(size_t)ch * (kMomHist + n_blk) * 10 + t] = hm[(size_t)ch * kMomHist * 10 + t];
     if (t < kCicHist)
         reinterpret_cast<uint32_t *>(cic)[(size_t)ch * (kCicHist + n_blk) + t] =
@@ -564,9 +567,9 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
     const uint32_t nch = ctx->cfg.n_channels, total = n_blk * nch, nf = n_blk / 2;
     hipStream_t st = ctx->stream;
     ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, mom, cic, comp,
-                                                 n_blk);
-    const uint32_t *cin = ctx->d_carry[ctx->carry_sel];
-    uint32_t *cout = ctx->d_carry[ctx->carry_sel ^ 1];
+                                                 n_blk, ctx->d_carry[0], ctx->d_carry[1]);
+    const uint32_t *cin = ctx->d_carry[1];
+    uint32_t *cout = ctx->d_carry[0];
     if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
     ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
         adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, mom, ctx->d_nco_tab);
@@ -585,8 +588,6 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
         ddc::ddc_adc_minmax<<<dim3(gx, nch), 256, 0, st>>>(adc12, row_bytes, pieces, ctx->d_adc_min, ctx->d_adc_max);
     }
     const hipError_t e = hipGetLastError();
-    // the ingest kernel is queued: the saved carries now belong to the other buffer whatever follows
-    ctx->carry_sel ^= 1;
     if (e != hipSuccess) return fail(ctx, -EIO, std::string("RX launch: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1402,7 +1403,7 @@ std::vector<StateSeg> state_segments(ddc_ctx *ctx)
 {
     const size_t n = ctx->cfg.n_channels;
     return {
-        { ctx->d_acc, n * 4 }, { ctx->d_phi, n * 4 }, { ctx->d_carry[ctx->carry_sel], n * 24 },
+        { ctx->d_acc, n * 4 }, { ctx->d_phi, n * 4 }, { ctx->d_carry[0], n * 24 },
         { ctx->d_hist_mom, n * ddc::kMomHist * 10 * sizeof(unsigned long long) },
         { ctx->d_hist_cic, n * ddc::kCicHist * 4 }, { ctx->d_hist_comp, n * ddc::kCompHist * 4 },
         { ctx->tx.d_acc, n * 4 }, { ctx->tx.d_hist_x, n * ddc::kTxXHist * 4 }, { ctx->tx.d_hist_y, n * ddc::kTxYHist * 4 },
