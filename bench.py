@@ -395,6 +395,19 @@ def main(argv=None):
                 "hbm_frac_at_issue_roof": round(BYTES_PER_CHANNEL_SAMPLE * nch * S / roof_s / 1e9 / HBM_PEAK_GBS, 4),
                 "source": "%s @ commit %s" % (valu["source"], valu.get("commit", "?")),
             }
+            if valu.get("issue_cycles_mixed"):
+                # the two classes only reach their own rates in streams of one class; a stream with this
+                # kernel's mix, every instruction independent, issues at one rate whatever the class
+                # (probe rows front_mix_spread / front_mix_runs): the roof of the mixed stream
+                need_mx = valu["insts_per_sample"] * valu["issue_cycles_mixed"] * waves
+                roof_mx = need_mx / (N_SIMD * valu["clock_ghz"] * 1e9)
+                roof["valu"]["mixed_stream"] = {
+                    "issue_cycles_per_inst": valu["issue_cycles_mixed"],
+                    "issue_cycles_per_inst_fast_in_runs": valu.get("issue_cycles_mixed_runs"),
+                    "issue_util": round(need_mx / have, 4),
+                    "launch_ms_at_issue_roof": round(roof_mx * 1e3, 4),
+                    "hbm_frac_at_issue_roof": round(BYTES_PER_CHANNEL_SAMPLE * nch * S / roof_mx / 1e9 / HBM_PEAK_GBS, 4),
+                }
             roof["closer_roof"] = "valu-issue" if need / have > achieved / HBM_PEAK_GBS else "hbm"
         res = {
             "metric": METRIC,

@@ -326,8 +326,8 @@ int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
  * float[6][6], "hpf_v" float[6][7], "lpf_k" float[32][11], "lpf_v" float[32][12],
  * "lpf_stages" / "hpf_hz" / "lpf_hz" int[], "sql_hpf_k" float[6], "sql_hpf_v" float[7]
  * (STM32/Src/audio_filters.c:41-126), "zoom_biquad" double[4][20], "zoom_fir"
- * double[4][4] (fft.c:72-183), "nco_coarse" uint32[2048][2] ({2 sc | 2 cc << 16,
- * 2 cc | -2 sc << 16} of the coarse ROMs), "nco_fine_sine" int16[2048] (the kernels'
+ * double[4][4] (fft.c:72-183), "nco_coarse" uint32[2048][2] ({2 cc | 2 sc << 16,
+ * -2 sc | 2 cc << 16} of the coarse ROMs), "nco_fine_sine" int16[2048] (the kernels'
  * arithmetic form of the fine sine ROM).  out = NULL only reports the size. */
 int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes);
 

@@ -55,8 +55,8 @@ def test_library_nco_tables_are_the_reference_roms(ddc):
     sc, cc = REF["nco_sin_c"].astype(np.int64), REF["nco_cos_c"].astype(np.int64)
     lo = lambda w: ((w & 0xFFFF) ^ 0x8000).astype(np.int64) - 0x8000
     hi = lambda w: ((w >> 16) ^ 0x8000).astype(np.int64) - 0x8000
-    assert np.array_equal(lo(t[:, 0]), 2 * sc) and np.array_equal(hi(t[:, 0]), 2 * cc)
-    assert np.array_equal(lo(t[:, 1]), 2 * cc) and np.array_equal(hi(t[:, 1]), -2 * sc)
+    assert np.array_equal(lo(t[:, 0]), 2 * cc) and np.array_equal(hi(t[:, 0]), 2 * sc)
+    assert np.array_equal(lo(t[:, 1]), -2 * sc) and np.array_equal(hi(t[:, 1]), 2 * cc)
     assert np.array_equal(ddc.debug_table("nco_fine_sine", np.int16), REF["nco_sin_f"])
     assert np.all(REF["nco_cos_f"] == 8191)
 

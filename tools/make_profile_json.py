@@ -26,8 +26,12 @@ SRC = os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_rx_kernels.h
 KERNEL = "ddc::ddc_rx_front"
 # issue classes (profiles/r02_valu_issue_probe.txt): ~2.1 cycles per wave-instruction per SIMD
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32", "v_or_b32",
-        "v_xor_b32", "v_mov_b32", "v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_mul_lo_u16", "v_add_u16"}
+        "v_xor_b32", "v_mov_b32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32", "v_mul_f32", "v_add_f32",
+        "v_mul_lo_u16", "v_add_u16"}
 ISSUE_FAST, ISSUE_SLOW = 2.15, 4.07
+# a stream with the kernel's class mix (22 : 10 in 32, all independent) at 3 waves per SIMD: the 2-cycle
+# instructions spread among the others / in one run (probe rows front_mix_spread, front_mix_runs)
+ISSUE_MIXED, ISSUE_MIXED_RUNS = 4.15, 3.90
 
 
 def medians(path, kernel):
@@ -112,7 +116,8 @@ def main():
                  "tools/probe/valu_issue.hip, profiles/r02_valu_issue_probe.txt)" % loop_n,
                  sq_insts_valu=m["SQ_INSTS_VALU"], insts_per_sample=round(per_sample, 3),
                  slow_per_sample=round(per_sample * fs, 3), fast_per_sample=round(per_sample * ff, 3),
-                 issue_cycles_slow=ISSUE_SLOW, issue_cycles_fast=ISSUE_FAST, clock_ghz=a.clock_ghz,
+                 issue_cycles_slow=ISSUE_SLOW, issue_cycles_fast=ISSUE_FAST,
+                 issue_cycles_mixed=ISSUE_MIXED, issue_cycles_mixed_runs=ISSUE_MIXED_RUNS, clock_ghz=a.clock_ghz,
                  sq_wave_cycles=m.get("SQ_WAVE_CYCLES"), sq_busy_cycles=m.get("SQ_BUSY_CYCLES"),
                  grbm_gui_active=m.get("GRBM_GUI_ACTIVE"))
         json.dump(v, open(os.path.join(ROOT, "profiles", "valu.json"), "w"), indent=1)

@@ -34,7 +34,7 @@ struct Stamp { uint64_t cycles, realtime; };
 extern __shared__ uint32_t dyn_lds[];
 
 // destinations %0..%7 (TYPE wide), sources %8 (TYPE) %9 (32 bit) vector, %10 scalar
-#define DEFK(NAME, OP, TYPE)                                                                         \
+#define DEFB(NAME, BODY, TYPE)                                                                       \
     __global__ __launch_bounds__(256) void k_##NAME(Stamp *out, int iters, uint32_t seed)             \
     {                                                                                                \
         TYPE r0 = seed + threadIdx.x, r1 = r0 * 3u, r2 = r0 * 5u, r3 = r0 * 7u, r4 = r0 * 9u,        \
@@ -46,7 +46,7 @@ extern __shared__ uint32_t dyn_lds[];
         const uint64_t t0 = __builtin_amdgcn_s_memtime();                                            \
         const uint64_t q0 = __builtin_amdgcn_s_memrealtime();                                        \
         for (int i = 0; i < iters; i++) {                                                            \
-            asm volatile(BLOCK32(OP)                                                                 \
+            asm volatile(BODY                                                                        \
                          : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) \
                          : "v"(a), "v"(b), "s"(sc)                                                   \
                          : "vcc");                                                                   \
@@ -62,6 +62,7 @@ extern __shared__ uint32_t dyn_lds[];
         if ((uint32_t)(r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7) == 0x9E3779B9u && seed == 77u)          \
             out[0].cycles = (uint64_t)b;                                                             \
     }
+#define DEFK(NAME, OP, TYPE) DEFB(NAME, BLOCK32(OP), TYPE)
 #define DEF32(NAME, OP) DEFK(NAME, OP, uint32_t)
 #define DEF64(NAME, OP) DEFK(NAME, OP, uint64_t)
 
@@ -191,6 +192,34 @@ DEF32(xad_u32, OP_XAD)
 DEF32(dot2_then_add, OP_DOT2_ADD)
 DEF32(dot2_then_fma, OP_DOT2_FMA)
 DEF32(perm_then_add, OP_PERM_ADD)
+// the class mix of the ddc_rx_front loop (22 of the 4-cycle kind, 10 of the 2-cycle kind in 32),
+// all independent: once spread evenly, once with the 2-cycle instructions in one run
+#define OP_FMAMK(d)    "v_fmamk_f32 " D(d) ", " D(d) ", 0x58c90800, %8\n"
+#define MIX_SPREAD "v_dot2_i32_i16 %0, %8, %9, %0\n v_mul_i32_i24 %1, %8, %1\n v_add_u32 %2, %8, %2\n" \
+    "v_perm_b32 %3, %3, %8, %9\n v_dot2c_i32_i16 %4, %8, %9\n v_lshrrev_b32 %5, 13, %5\n" \
+    "v_pk_add_u16 %6, %6, %8\n v_bfe_i32 %7, %7, 4, 12\n v_and_b32 %0, 0x3ff8, %0\n" \
+    "v_dot2_i32_i16 %1, %8, %9, %1\n v_dot2c_i32_i16 %2, %8, %9\n v_fma_f32 %3, %8, %9, %3\n" \
+    "v_mul_i32_i24 %4, %8, %4\n v_dot2c_i32_i16 %5, %8, %9\n v_add_u32 %6, %8, %6\n" \
+    "v_perm_b32 %7, %7, %8, %9\n v_dot2c_i32_i16 %0, %8, %9\n v_and_b32 %1, 0x3ff8, %1\n" \
+    "v_dot2c_i32_i16 %2, %8, %9\n v_dot2_i32_i16 %3, %8, %9, %3\n v_lshrrev_b32 %4, 13, %4\n" \
+    "v_dot2c_i32_i16 %5, %8, %9\n v_mul_i32_i24 %6, %8, %6\n v_ashrrev_i32 %7, 16, %7\n" \
+    "v_dot2c_i32_i16 %0, %8, %9\n v_pk_add_u16 %1, %1, %8\n v_add_u32 %2, %8, %2\n" \
+    "v_dot2c_i32_i16 %3, %8, %9\n v_bfe_i32 %4, %4, 4, 12\n v_dot2c_i32_i16 %5, %8, %9\n" \
+    "v_fma_f32 %6, %8, %9, %6\n v_dot2c_i32_i16 %7, %8, %9\n"
+#define MIX_RUNS "v_add_u32 %0, %8, %0\n v_lshrrev_b32 %1, 13, %1\n v_and_b32 %2, 0x3ff8, %2\n" \
+    "v_and_b32 %3, 0x3ff8, %3\n v_fma_f32 %4, %8, %9, %4\n v_add_u32 %5, %8, %5\n v_lshrrev_b32 %6, 13, %6\n" \
+    "v_and_b32 %7, 0x3ff8, %7\n v_fma_f32 %0, %8, %9, %0\n v_ashrrev_i32 %1, 16, %1\n" \
+    "v_dot2_i32_i16 %2, %8, %9, %2\n v_dot2_i32_i16 %3, %8, %9, %3\n v_mul_i32_i24 %4, %8, %4\n" \
+    "v_mul_i32_i24 %5, %8, %5\n v_perm_b32 %6, %6, %8, %9\n v_pk_add_u16 %7, %7, %8\n" \
+    "v_bfe_i32 %0, %0, 4, 12\n v_bfe_i32 %1, %1, 4, 12\n v_dot2_i32_i16 %2, %8, %9, %2\n" \
+    "v_perm_b32 %3, %3, %8, %9\n v_pk_add_u16 %4, %4, %8\n v_mul_i32_i24 %5, %8, %5\n" \
+    "v_dot2c_i32_i16 %6, %8, %9\n v_dot2c_i32_i16 %7, %8, %9\n v_dot2c_i32_i16 %0, %8, %9\n" \
+    "v_dot2c_i32_i16 %1, %8, %9\n v_dot2c_i32_i16 %2, %8, %9\n v_dot2c_i32_i16 %3, %8, %9\n" \
+    "v_dot2c_i32_i16 %4, %8, %9\n v_dot2c_i32_i16 %5, %8, %9\n v_dot2c_i32_i16 %6, %8, %9\n" \
+    "v_dot2c_i32_i16 %7, %8, %9\n"
+DEF32(fmamk_f32_literal, OP_FMAMK)
+DEFB(front_mix_spread, MIX_SPREAD, uint32_t)
+DEFB(front_mix_runs, MIX_RUNS, uint32_t)
 
 #define OP64_ADDF64(d)  "v_add_f64 " D(d) ", " D(d) ", %8\n"
 #define OP64_FMAF64(d)  "v_fma_f64 " D(d) ", " D(d) ", %8, %8\n"
@@ -354,7 +383,7 @@ int main(int argc, char **argv)
         T(mad_legacy_u16), T(dot4_i32_i8), T(dot8_i32_i4), T(pk_mul_lo_u16), T(pk_mad_i16), T(pk_ashrrev_i16),
         T(pk_lshlrev_b16), T(pk_fma_f16), T(cvt_f32_i32), T(cvt_i32_f32), T(cvt_f32_ubyte1), T(cvt_pk_i16_i32),
         T(mov_b32_dpp), T(add_u32_dpp), T(add_u32_sdwa), T(lshlrev_b32_sdwa), T(cndmask_b32), T(sad_u32), T(xad_u32),
-        T2(dot2_then_add), T2(dot2_then_fma), T2(perm_then_add),
+        T2(dot2_then_add), T2(dot2_then_fma), T2(perm_then_add), T(fmamk_f32_literal), T(front_mix_spread), T(front_mix_runs),
         T(add_f64), T(fma_f64), T(lshlrev_b64), T(mad_u64_u32), T(pk_fma_f32), T(pk_add_f32),
 #undef T
 #undef T2
@@ -365,7 +394,10 @@ int main(int argc, char **argv)
     printf(" |");
     for (int w : kW) printf("  W=%d  ", w);
     printf(" | GHz at W=4\n");
-    for (auto &t : tests) run_plain(t.name, t.k, t.per_iter, iters);
+    const char *only = argc > 2 ? argv[2] : nullptr; // optional: only the cases whose name contains this
+    for (auto &t : tests)
+        if (!only || strstr(t.name, only)) run_plain(t.name, t.k, t.per_iter, iters);
+    if (only) return 0;
     printf("cycles per {1 ds_read_b64 (NCO-table fetch) + 4 plain VALU + N dot2} per SIMD, lanes `stride` entries apart\n");
     run_lds<0>("ds_read + 0 dot2", iters / 4);
     run_lds<8>("ds_read + 8 dot2", iters / 4);

@@ -107,14 +107,14 @@ int build_nco_table(std::vector<uint2> &tab)
     for (int i = 0; i < 2048; i++) {
         const int sc = (int)rnd_half_away(8191.0 * std::sin(two_pi * i / 2048.0));
         const int cc = (int)rnd_half_away(8191.0 * std::cos(two_pi * i / 2048.0));
-        tab[i].x = ddc::pack_w(2 * sc, 2 * cc);
-        tab[i].y = ddc::pack_w(2 * cc, -2 * sc);
+        tab[i].x = ddc::pack_w(2 * cc, 2 * sc);
+        tab[i].y = ddc::pack_w(-2 * sc, 2 * cc);
     }
     for (uint32_t fi = 0; fi < 2048; fi++) {
         const long sf = rnd_half_away(8191.0 * std::sin(two_pi * fi / 4194304.0));
         const long cf = rnd_half_away(8191.0 * std::cos(two_pi * fi / 4194304.0));
         if ((long)((fi * DDC_SF_K + DDC_SF_R) >> 24) != sf || cf != 8191) return -1;
-        if ((long)((32u * fi * DDC_SF16_K + DDC_SF16_R) >> 24) != sf) return -1;
+        if (ddc::nco_fine_pair(fi) != ((8191u << 16) | (uint32_t)sf)) return -1;
     }
     return 0;
 }
@@ -1556,13 +1556,13 @@ int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
     TAB("zoom_biquad", kZoomBiquad)
     TAB("zoom_fir", kZoomFir)
 #undef TAB
-    if (k == "nco_coarse") {          // as uploaded for the kernels: {2 sc | 2 cc << 16, 2 cc | -2 sc << 16}
+    if (k == "nco_coarse") {          // as uploaded for the kernels: {2 cc | 2 sc << 16, -2 sc | 2 cc << 16}
         if (build_nco_table(nco) != 0) return fail(nullptr, -EFAULT, "fine-sine shortcut does not reproduce the NCO fine ROM");
         src = nco.data();
         n = nco.size() * sizeof(uint2);
     } else if (k == "nco_fine_sine") { // the kernels' arithmetic fine sine for every 11-bit fine phase
         fine.resize(2048);
-        for (uint32_t f = 0; f < 2048; f++) fine[f] = (int16_t)((32u * f * DDC_SF16_K + DDC_SF16_R) >> 24);
+        for (uint32_t f = 0; f < 2048; f++) fine[f] = (int16_t)(ddc::nco_fine_pair(f) & 0xFFFFu);
         src = fine.data();
         n = fine.size() * sizeof(int16_t);
     }

@@ -82,11 +82,21 @@ __device__ __forceinline__ int dot2_sconst(unsigned a, unsigned w, int c)
     return r;
 }
 
-// Fine sine of the NCO from the fine phase f (11 bits) given as 32 f in a 16-bit
-// half: (32 f * 6433 + 2^23) >> 24 reproduces the fine ROM round(8191 sin(2 pi f / 2^22))
-// for every f (checked on the host when a ctx is created).
-#define DDC_SF16_K 6433u
-#define DDC_SF16_R 8388608u
+// Fine sine of the NCO in one float multiply-add.  The fine phase f (11 bits),
+// read as a float, is the denormal f * 2^-149.  The float D with bit pattern
+// 0x1FFF0000 has ulp 2^-87, so fma(f * 2^-149, 32 K * 2^62, D) = D + 32 f K ulp,
+// rounded to nearest, carries the bit pattern 0x1FFF0000 + round(32 f K): the
+// pair {fine sine, 8191} of 16-bit halves the NCO's dot products want.  With
+// K = 6433 / 2^24 that is the fine ROM round(8191 sin(2 pi f / 2^22)) for every
+// f (checked on the host when a ctx is created).  Needs denormals kept and
+// round-to-nearest, the mode HIP kernels run in.
+#define DDC_SF_FMA_C 0x1.921p55f          /* 6433 * 2^43 = 32 * 6433 / 2^24 * 2^62 */
+#define DDC_SF_FMA_D_BITS 0x1FFF0000u
+__host__ __device__ __forceinline__ uint32_t nco_fine_pair(uint32_t f)
+{
+    const float x = __builtin_bit_cast(float, f);
+    return __builtin_bit_cast(uint32_t, __builtin_fmaf(x, DDC_SF_FMA_C, __builtin_bit_cast(float, DDC_SF_FMA_D_BITS)));
+}
 
 // signed bit-field extract kept as one instruction (the compiler otherwise folds
 // it into a shift of the multiplicand and pays for that in the 12-bit unpack)
@@ -98,20 +108,23 @@ __device__ __forceinline__ int sbfe_c(int v)
     return r;
 }
 
-// NCO, first half: coarse-table fetch and the packed {8191, fine sine} operand.
-// tab: 2048 coarse entries {2*sc | 2*cc<<16, 2*cc | (-2*sc)<<16}.  acc27 holds
-// the 22-bit phase accumulator in bits 26..5 (bits above are ignored), so its low
-// half is 32 * fine phase, ready for a 16-bit multiply-add.
-__device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc27, uint2 &e, uint32_t &w)
+// NCO, first half: coarse-table fetch and the packed {fine sine, 8191} operand.
+// tab: 2048 coarse entries {2*cc | 2*sc<<16, -2*sc | 2*cc<<16}.  acc30 holds
+// the 22-bit phase accumulator in bits 29..8 (bits above are ignored, bits below
+// are zero): its high half is the coarse phase times eight, the byte offset of
+// the table entry, apart from the two bits on top, so one instruction that reads
+// the high half and masks makes the address; the fine phase is bits 18..8.
+__device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc30, uint2 &e, uint32_t &w)
 {
-    const uint32_t off = (acc27 >> 13) & 0x3FF8u;
+    uint32_t off, f;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(off) : "v"(acc30), "v"(0x3FF8u));
+    asm("v_bfe_u32 %0, %1, 8, 11" : "=v"(f) : "v"(acc30));
     e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off);
-    uint32_t t; // t >> 24 = fine sine (0..25)
-    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(t) : "v"(acc27), "s"(DDC_SF16_K), "v"(DDC_SF16_R));
-    w = __builtin_amdgcn_perm(t, 0x1FFFu, 0x0C070100u);       // {8191, t>>24}
+    w = nco_fine_pair(f);
 }
 
-// NCO second half + mixer: 2*(sc*8191 + cc*sf + 4096) has the 12-bit mixer
+// NCO second half + mixer: 2*(cc*sf + sc*8191 + 4096) has the 12-bit mixer
 // operand (14-bit output >> 2) in bits 31..16.  Returns the two 24-bit mixer
 // products adc * nco12; the CIC input is x = wrap23(product) >> 8.
 __device__ __forceinline__ void nco_finish(const uint2 e, uint32_t w, int adc, int &pi, int &pq)
@@ -166,6 +179,14 @@ __device__ __forceinline__ void unpack8(uint32_t d0, uint32_t d1, uint32_t d2, i
     a[7] = (int)d2 >> 20;
 }
 
+// acc += v for a 64-bit sum and a 32-bit signed addend as one instruction (the
+// compiler's choice is a shift for the sign word and a 64-bit add).
+__device__ __forceinline__ void add_sext(long long &acc, int v)
+{
+    unsigned long long carry;
+    asm("v_mad_i64_i32 %0, %1, %2, 1, %0" : "+v"(acc), "=s"(carry) : "v"(v));
+}
+
 // Running sums over the chunk steps of one window.  T[i][q] ends as
 // sum_a C(a'+q, q) mu_i(a); the widths are the smallest that provably hold the
 // value for doubled 15-bit inputs (cascade_widths() in tools/cic_math.py).
@@ -179,11 +200,11 @@ struct Cascade {
     }
     __device__ __forceinline__ void step(const int (&mu)[5])
     {
-        t00 += mu[0]; t01 += t00; t02 += t01; t03 += t02; t04 += t03;
-        t10 += mu[1]; t11 += t10; t12 += t11; t13 += t12;
-        t20 += mu[2]; t21 += t20; t22 += t21;
-        t30 += mu[3]; t31 += t30;
-        t40 += mu[4];
+        t00 += mu[0]; t01 += t00; t02 += t01; add_sext(t03, t02); t04 += t03;
+        t10 += mu[1]; t11 += t10; add_sext(t12, t11); t13 += t12;
+        t20 += mu[2]; add_sext(t21, t20); t22 += t21;
+        add_sext(t30, mu[3]); t31 += t30;
+        add_sext(t40, mu[4]);
     }
     // Adds what a step with local moments mu, taken before the sixteen steps this
     // cascade has run, would have left behind: C(16 + q, q) * mu[i] in T[i][q].
@@ -271,21 +292,34 @@ __device__ __forceinline__ void tail5_acc(const unsigned (&pk)[3], int (&m)[5])
     }
 }
 
+// The phases of two neighbouring samples advance together as one 64-bit sum
+// (even sample in the low dword, odd in the high): a carry out of the low dword
+// lands in bit 0 of the high one, below the phase field (bits 29..8), and a block
+// of 512 samples produces fewer than 2^7 of them.
+__device__ __forceinline__ unsigned long long pair_add(unsigned long long a, unsigned long long b)
+{
+    unsigned long long r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int G>
 __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d1, uint32_t d2,
-                                       uint32_t &acc32, uint32_t phi32, int (&mi)[5], int (&mq)[5],
+                                       unsigned long long &accp, unsigned long long phi2, int (&mi)[5], int (&mq)[5],
                                        unsigned (&last_i)[3], unsigned (&last_q)[3])
 {
     int a[8];
     unpack8(d0, d1, d2, a);
     uint2 e[8];
     uint32_t w[8];
+    unsigned long long p = accp;
 #pragma unroll
-    for (int k = 0; k < 8; k++) nco_fetch(tab, acc32 + (uint32_t)k * phi32, e[k], w[k]);
-    acc32 += 8u * phi32;
-    // keep the running phase opaque: otherwise all 32 multiples of phi32 of a
-    // chunk are hoisted into registers of their own
-    asm volatile("" : "+v"(acc32));
+    for (int k = 0; k < 4; k++) {
+        nco_fetch(tab, (uint32_t)p, e[2 * k], w[2 * k]);
+        nco_fetch(tab, (uint32_t)(p >> 32), e[2 * k + 1], w[2 * k + 1]);
+        p = pair_add(p, phi2);
+    }
+    accp = p;
     unsigned pi[4], pq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -367,10 +401,12 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
     const uint32_t gc = active ? g : total_blocks - 1;
     const uint32_t ch = gc / n_blk, b = gc - ch * n_blk;
     // phase and increment come in shifted left by 10 (32-bit wrap = accumulator
-    // wrap); the sample loop runs on the << 5 form nco_fetch wants
+    // wrap); the sample loop runs on the << 8 form nco_fetch wants
     const uint32_t phi_in = phi32v[ch];
-    const uint32_t phi32 = phi_in >> 5;
-    uint32_t acc32 = (acc0[ch] + (b * (uint32_t)kBlk) * phi_in) >> 5;
+    const uint32_t phi32 = phi_in >> 2;
+    const uint32_t acc32 = (acc0[ch] + (b * (uint32_t)kBlk) * phi_in) >> 2;
+    unsigned long long accp = (unsigned long long)acc32 | ((unsigned long long)(acc32 + phi32) << 32);
+    const unsigned long long phi2 = (unsigned long long)(2u * phi32) | ((unsigned long long)(2u * phi32) << 32);
 
 #pragma unroll
     for (int j = 0; j < 8; j++) lds_dma16(src[j], &lines[(wave_base + 8 * j) * 8]);
@@ -417,10 +453,10 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
             }
         }
         int mi[5], mq[5];
-        group8<0>(tab, v0.x, v0.y, v0.z, acc32, phi32, mi, mq, last_i, last_q);
-        group8<1>(tab, v0.w, v1.x, v1.y, acc32, phi32, mi, mq, last_i, last_q);
-        group8<2>(tab, v1.z, v1.w, v2.x, acc32, phi32, mi, mq, last_i, last_q);
-        group8<3>(tab, v2.y, v2.z, v2.w, acc32, phi32, mi, mq, last_i, last_q);
+        group8<0>(tab, v0.x, v0.y, v0.z, accp, phi2, mi, mq, last_i, last_q);
+        group8<1>(tab, v0.w, v1.x, v1.y, accp, phi2, mi, mq, last_i, last_q);
+        group8<2>(tab, v1.z, v1.w, v2.x, accp, phi2, mi, mq, last_i, last_q);
+        group8<3>(tab, v2.y, v2.z, v2.w, accp, phi2, mi, mq, last_i, last_q);
         ci.step(mi);
         cq.step(mq);
     }
@@ -460,7 +496,7 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
                 adc + (size_t)ch * row_bytes + (size_t)b * kBlkBytes - 12);
             int a[8];
             unpack8(p[0], p[1], p[2], a);
-            uint32_t ph = (acc0[ch] + (b * (uint32_t)kBlk - 6u) * phi_in) >> 5;
+            uint32_t ph = (acc0[ch] + (b * (uint32_t)kBlk - 6u) * phi_in) >> 2;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 int pi0, pq0, pi1, pq1;

@@ -203,10 +203,10 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
         wi.start<504, 0>(y5);
         wq.start<504, 1>(y5);
     }
-    // stored phase / increment are << 10; the sample loop runs on the << 5 form of nco_fetch
+    // stored phase / increment are << 10; the sample loop runs on the << 8 form of nco_fetch
     const uint32_t phi_in = phi32v[ch];
-    const uint32_t phi32 = phi_in >> 5;
-    uint32_t ph = (acc0[ch] + (512u * (g - 1) - 2u) * phi_in) >> 5;
+    const uint32_t phi32 = phi_in >> 2;
+    uint32_t ph = (acc0[ch] + (512u * (g - 1) - 2u) * phi_in) >> 2;
     const uint32_t mine = tid * 8u, swz = line_swz(tid);
     __syncthreads(); // tab is ready
 #pragma unroll 1
