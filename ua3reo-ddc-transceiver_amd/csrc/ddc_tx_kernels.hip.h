@@ -19,7 +19,7 @@
  *
  * The kernel writes 2 bytes per DAC sample and reads 4 bytes per 1024 samples;
  * like the RX ingest it is bound by vector-ALU issue (NCO + two exact
- * polynomial walks per sample, run in double precision).
+ * polynomial walks per sample on 64-bit integers).
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -75,15 +75,17 @@ __device__ __forceinline__ void nco14(const uint2 *tab, uint32_t acc32, int &s14
 
 // Running-sum walk of the interpolated tx_cic output over one segment,
 //   P(u) = sum_q p_q(u) y[G-1-q],  p_q(u) = sum_e COEF[q][e] C(u+e, e) = h[512 q + u]  (u = 0..511),
-// by its backward differences: one step is four additions.
+// by its backward differences: one step is four 64-bit additions.
 //
 // p_q(u) are the taps of (1,...,1)_512^{*5}: non-negative, and the five of one u
-// sum to 2^36.  So |P| <= 2^51 for 16-bit y, and P, its differences and every
-// partial sum of the start values below are integers a double holds exactly:
-// the walk runs as v_add_f64 (one issue slot each; a 64-bit integer add costs
-// two) and is started with 25 v_fma_f64 per branch.  p carries P + 1/2 - 2^37,
-// still exact, so that adding 1.5 * 2^90 rounds it (to nearest, never a tie) to
-// 2^38 * floor(P / 2^38) and leaves floor(P >> 38) in the low dword of the sum.
+// sum to 2^36.  So |P| <= 2^51 for 16-bit y.  The start values are sums of at
+// most 25 products of a constant and a 16-bit word and lie in [-2^51, 2^51)
+// (checked at compile time): they are formed in double precision (exact, 25
+// v_fma_f64 per branch), turned into integers by adding 1.5 * 2^52 and
+// subtracting that number's bit pattern, and scaled by 2^10.  The walk itself
+// runs on those 64-bit integers (one v_lshl_add_u64 per addition), and the
+// tx_cic output register, bits 51..38 of P, is the signed upper half of the high
+// dword of 2^10 P: the multiply that consumes it selects that half for free.
 __host__ __device__ constexpr long long tx_start_const(int u, int k, int q)
 {
     // nabla^k p_q(u) = sum_{e>=k} COEF[q][e] C(u + e - k, e - k)
@@ -93,23 +95,24 @@ __host__ __device__ constexpr long long tx_start_const(int u, int k, int q)
 }
 constexpr bool tx_start_consts_exact()
 {
-    for (int u = 0; u <= 504; u += 504)
+    // every start value (and every partial sum on the way to it) must lie in [-2^51, 2^51)
+    // for words in [-32768, 32767]
+    for (int u : { 0, 504 })
         for (int k = 0; k < 5; k++) {
-            long long mag = 0;
+            long long pos = 0, neg = 0;
             for (int q = 0; q < 5; q++) {
                 const long long v = tx_start_const(u, k, q);
-                mag += v < 0 ? -v : v;
+                if (v < 0) neg -= v; else pos += v;
             }
-            if (mag * 32768 >= (1ll << 52)) return false;
+            if (pos * 32767 + neg * 32768 >= (1ll << 51)) return false;
+            if (pos * 32768 + neg * 32767 > (1ll << 51)) return false;
         }
     return true;
 }
-static_assert(tx_start_consts_exact(), "a start value of the TX walk would not be exact in double precision");
+static_assert(tx_start_consts_exact(), "a start value of the TX walk would leave [-2^51, 2^51)");
 
 struct PolyWalk {
-    double q3, q2, q1, p, c4;
-    static constexpr double kBias = 0.5 - 137438953472.0; // 1/2 - 2^37
-    static constexpr double kMagic = 0x1.8p+90;           // 1.5 * 2^90
+    unsigned long long q3, q2, q1, p, c4; // 2^10 times the polynomial and its differences, mod 2^64
     // state at u = U (0 or 504) of the segment whose newest input word is y[0]
     // (y[q] = q words older); B = 0 takes the I halves, 1 the Q halves
     template <int U, int B>
@@ -118,7 +121,8 @@ struct PolyWalk {
         double v[5];
 #pragma unroll
         for (int q = 0; q < 5; q++) v[q] = (double)(B ? (int)y[q] >> 16 : (int)(int16_t)(y[q] & 0xFFFFu));
-        double a[5] = { kBias, 0.0, 0.0, 0.0, 0.0 };
+        constexpr double kToInt = 0x1.8p+52; // 1.5 * 2^52: an integer below 2^51 in magnitude lands in the mantissa
+        double a[5] = { kToInt, kToInt, kToInt, kToInt, kToInt };
 #pragma unroll
         for (int k = 0; k < 5; k++)
 #pragma unroll
@@ -126,17 +130,21 @@ struct PolyWalk {
                 const double c = (double)tx_start_const(U, k, q);
                 if (c != 0.0) a[k] = __builtin_fma(c, v[q], a[k]);
             }
-        p = a[0]; q1 = a[1]; q2 = a[2]; q3 = a[3]; c4 = a[4];
+        unsigned long long w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            w[k] = (__builtin_bit_cast(unsigned long long, a[k]) - __builtin_bit_cast(unsigned long long, kToInt)) << 10;
+        p = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3]; c4 = w[4];
     }
     __device__ __forceinline__ void next()
     {
-        q3 += c4;
-        q2 += q3;
-        q1 += q2;
-        p += q1;
+        q3 = pair_add(q3, c4);
+        q2 = pair_add(q2, q3);
+        q1 = pair_add(q1, q2);
+        p = pair_add(p, q1);
     }
-    // tx_cic output register: bits 59..46 of the 2^8-scaled sum = P >> 38
-    __device__ __forceinline__ int out14() const { return __double2loint(p + kMagic); }
+    // tx_cic output register: bits 59..46 of the 2^8-scaled sum = P >> 38 = bits 63..48 of 2^10 P
+    __device__ __forceinline__ int out14() const { return (int)(uint32_t)(p >> 32) >> 16; }
 };
 
 /*
@@ -206,7 +214,10 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
     // stored phase / increment are << 10; the sample loop runs on the << 8 form of nco_fetch
     const uint32_t phi_in = phi32v[ch];
     const uint32_t phi32 = phi_in >> 2;
-    uint32_t ph = (acc0[ch] + (512u * (g - 1) - 2u) * phi_in) >> 2;
+    const uint32_t ph0 = (acc0[ch] + (512u * (g - 1) - 2u) * phi_in) >> 2;
+    // even / odd sample phases as the two dwords of one 64-bit sum (see group8 of the RX kernel)
+    unsigned long long php = (unsigned long long)ph0 | ((unsigned long long)(ph0 + phi32) << 32);
+    const unsigned long long phi2 = (unsigned long long)(2u * phi32) | ((unsigned long long)(2u * phi32) << 32);
     const uint32_t mine = tid * 8u, swz = line_swz(tid);
     __syncthreads(); // tab is ready
 #pragma unroll 1
@@ -218,16 +229,22 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
         }
         uint32_t w[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int s14, c14;
-            nco14(tab, ph, s14, c14);
-            const uint32_t sum = (uint32_t)(__mul24(wi.out14(), s14) + __mul24(wq.out14(), c14) + (8191 << 14));
-            // the DAC word is bits 27..14; two per dword
-            if (k & 1) w[k / 2] = ((sum << 2) & 0x3FFF0000u) | (w[k / 2] & ~0x3FFF0000u);
-            else w[k / 2] = __builtin_amdgcn_ubfe(sum, 14, 14);
-            ph += phi32;
-            wi.next();
-            wq.next();
+        for (int k = 0; k < 4; k++) {
+            uint32_t sum[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                int s14, c14;
+                nco14(tab, h ? (uint32_t)(php >> 32) : (uint32_t)php, s14, c14);
+                sum[h] = (uint32_t)(__mul24(wi.out14(), s14) + __mul24(wq.out14(), c14) + (8191 << 14));
+                wi.next();
+                wq.next();
+            }
+            php = pair_add(php, phi2);
+            // a DAC word is bits 27..14 of its sum; two per dword
+            uint32_t lo, hi;
+            asm("v_bfe_u32 %0, %1, 14, 14" : "=v"(lo) : "v"(sum[0]));
+            hi = sum[1] & 0x0FFFC000u;
+            asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(w[k]) : "v"(hi), "v"(lo));
         }
         obuf[mine + (((uint32_t)grp & 7u) ^ swz)] = make_uint4(w[0], w[1], w[2], w[3]);
         if ((grp & 7) == 7) {
