@@ -250,6 +250,14 @@ __global__ void ddc_rx_save_history(unsigned long long *hm, int16_t *hc, int16_t
     if (t == 0) acc0[ch] += samples_lo * phi32v[ch];
 }
 
+// The device's own evaluation of the fine-sine multiply-add for every fine phase
+// (a device or build that flushes denormals would get it wrong silently).
+__global__ void ddc_nco_fine_selfcheck(uint32_t *out)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < 2048) out[f] = nco_fine_pair(f);
+}
+
 // The synthetic bench signal of ddc_synth_adc on the device.  The noise generator
 // (xorshift64*) is a serial recurrence per channel: pass 1 walks it once per channel
 // and keeps the state at the start of every 512-sample segment, pass 2 fills the
@@ -346,6 +354,21 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     if (build_nco_table(tab) != 0) {
         ctx->err = "fine-sine shortcut does not reproduce the NCO fine ROM";
         return bail(-EFAULT);
+    }
+    {
+        // the kernels compute the fine sine with a float multiply-add on a denormal: have the
+        // device evaluate all 2048 phases once and compare with the host's (d_nco_tab is free until
+        // the table is uploaded just below)
+        std::vector<uint32_t> got(2048);
+        ddc::ddc_nco_fine_selfcheck<<<8, 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(ctx->d_nco_tab));
+        CREATE_TRY(hipGetLastError());
+        CREATE_TRY(hipMemcpyAsync(got.data(), ctx->d_nco_tab, 2048 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CREATE_TRY(hipStreamSynchronize(ctx->stream));
+        for (uint32_t f = 0; f < 2048; f++)
+            if (got[f] != ddc::nco_fine_pair(f)) {
+                ctx->err = "this device evaluates the NCO fine sine differently from the host (denormals flushed?)";
+                return bail(-EFAULT);
+            }
     }
     CREATE_TRY(hipMemcpyAsync(ctx->d_nco_tab, tab.data(), 2048 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
