@@ -200,6 +200,18 @@ int scratch_address(ddc_ctx *ctx, int device, unsigned char **out)
     return 0;
 }
 
+bool g_tables_ready[kMaxDevices] = {};
+bool device_tables_ready(int device)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    return device >= 0 && device < kMaxDevices && g_tables_ready[device];
+}
+void device_tables_mark_ready(int device)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (device >= 0 && device < kMaxDevices) g_tables_ready[device] = true;
+}
+
 // Byte offsets of the three work buffers inside one area, each 256-byte aligned.
 struct WorkLayout { size_t mom, cic, comp, total; };
 WorkLayout work_layout(size_t nch, size_t n_blk)
@@ -331,6 +343,10 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         }                                                                                    \
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
+    // the __constant__ tables are the same for every ctx: written once per device, by the first
+    // ctx created on it (a later ctx must not rewrite them under a running kernel of an earlier one)
+    const bool upload_tables = !device_tables_ready(cfg->device);
+#define CONST_TRY(call) do { if (upload_tables) CREATE_TRY(call); } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     if (scratch_address(ctx, cfg->device, &ctx->scratch_base) != 0) return bail(-EIO);
@@ -371,9 +387,9 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
             }
     }
     CREATE_TRY(hipMemcpyAsync(ctx->d_nco_tab, tab.data(), 2048 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
+    CONST_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
-    CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
+    CONST_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     {
         // compensator taps as the kernel multiplies them: pair m covers samples 2n - 64 + 2m, + 1
@@ -381,7 +397,7 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         for (int m = 0; m < 32; m++)
             cp[m] = (uint32_t)(uint16_t)rx_ciccomp_h[64 - 2 * m] | ((uint32_t)(uint16_t)rx_ciccomp_h[63 - 2 * m] << 16);
         cp[32] = (uint32_t)(uint16_t)rx_ciccomp_h[0];
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_ciccomp_pairs), cp, sizeof cp));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_ciccomp_pairs), cp, sizeof cp));
     }
     {
         // Hilbert taps as the kernel wants them: reversed pairs and the two low bit planes
@@ -393,12 +409,12 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
             odd[j >> 5] |= (c & 1u) << (j & 31);
             bit1[j >> 5] |= ((c >> 1) & 1u) << (j & 31);
         }
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs), pairs, sizeof pairs));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs), pairs, sizeof pairs));
         uint32_t padded[144] = {0};
         memcpy(padded + 3, pairs, sizeof pairs);
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs_pad), padded, sizeof padded));
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_odd), odd, sizeof odd));
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_bit1), bit1, sizeof bit1));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_pairs_pad), padded, sizeof padded));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_odd), odd, sizeof odd));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_hilb_bit1), bit1, sizeof bit1));
     }
     ctx->h_phi.assign(nch, 0);
     ctx->tx_dir.assign(nch, 0);
@@ -421,8 +437,8 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     CREATE_TRY(hipMemsetAsync(ctx->d_zoom, 0, nch * sizeof(ddc::ZoomState), ctx->stream));
     CREATE_TRY(hipMalloc(&ctx->d_audio_tx, nch * sizeof(ddc::TxAudioState)));
     CREATE_TRY(hipMemsetAsync(ctx->d_audio_tx, 0, nch * sizeof(ddc::TxAudioState), ctx->stream));
-    CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_i, sizeof tx_hilbert_i, 0));
-    CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_q, sizeof tx_hilbert_q, sizeof tx_hilbert_i));
+    CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_i, sizeof tx_hilbert_i, 0));
+    CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_q, sizeof tx_hilbert_q, sizeof tx_hilbert_i));
     {
         // Hamming window as the firmware evaluates it (fft.c:249-251) and the
         // 512-point twiddles
@@ -433,15 +449,17 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
             const double a = -2.0 * 3.14159265358979323846 * k / 512.0;
             tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_window), win.data(), 512 * sizeof(float)));
-        CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_twiddle), tw.data(), 256 * sizeof(float2)));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_window), win.data(), 512 * sizeof(float)));
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_twiddle), tw.data(), 256 * sizeof(float2)));
     }
     {
-        int rc = ddc_tx_state_create(&ctx->tx, ctx->cfg.n_channels, ctx->stream);
+        int rc = ddc_tx_state_create(&ctx->tx, ctx->cfg.n_channels, ctx->stream, upload_tables);
         if (rc != 0) { ctx->err = "TX state allocation failed"; return bail(rc); }
     }
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
+#undef CONST_TRY
 #undef CREATE_TRY
+    if (upload_tables) device_tables_mark_ready(cfg->device);
     *out = ctx;
     return 0;
 }

@@ -305,7 +305,8 @@ struct ddc_tx_state {
     size_t out_cap = 0;
 };
 
-inline int ddc_tx_state_create(ddc_tx_state *s, uint32_t n_channels, hipStream_t st)
+// upload_tables: also write the compensator taps into this device's __constant__ memory
+inline int ddc_tx_state_create(ddc_tx_state *s, uint32_t n_channels, hipStream_t st, bool upload_tables)
 {
     s->n_channels = n_channels;
     const size_t n = n_channels;
@@ -315,6 +316,7 @@ inline int ddc_tx_state_create(ddc_tx_state *s, uint32_t n_channels, hipStream_t
     if (hipMemsetAsync(s->d_acc, 0, n * 4, st) != hipSuccess) return -5;
     if (hipMemsetAsync(s->d_hist_x, 0, n * ddc::kTxXHist * 4, st) != hipSuccess) return -5;
     if (hipMemsetAsync(s->d_hist_y, 0, n * ddc::kTxYHist * 4, st) != hipSuccess) return -5;
+    if (!upload_tables) return 0;
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_tx_p1), tx_ciccomp_p1, sizeof tx_ciccomp_p1, 0,
                                hipMemcpyHostToDevice, st) != hipSuccess) return -5;
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_tx_p2), tx_ciccomp_p2, sizeof tx_ciccomp_p2, 0,
