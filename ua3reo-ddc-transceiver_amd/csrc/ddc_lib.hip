@@ -270,6 +270,22 @@ __global__ void ddc_nco_fine_selfcheck(uint32_t *out)
     if (f < 2048) out[f] = nco_fine_pair(f);
 }
 
+// The kernels' NCO (coarse table in LDS, fine sine, angle sums) evaluated for a run
+// of consecutive 22-bit phases: 14-bit sine and cosine.
+__global__ __launch_bounds__(256) void ddc_nco_sweep(const uint2 *__restrict__ nco_tab, uint32_t first_phase,
+                                                     uint32_t count, int16_t *__restrict__ s14, int16_t *__restrict__ c14)
+{
+    __shared__ uint2 tab[2048];
+    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tab[i] = nco_tab[i];
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        int s, c;
+        nco14(tab, ((first_phase + i) & 0x3FFFFFu) << 8, s, c);
+        s14[i] = (int16_t)s;
+        c14[i] = (int16_t)c;
+    }
+}
+
 // The synthetic bench signal of ddc_synth_adc on the device.  The noise generator
 // (xorshift64*) is a serial recurrence per channel: pass 1 walks it once per channel
 // and keeps the state at the start of every 512-sample segment, pass 2 fills the
@@ -1566,6 +1582,27 @@ int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
         ctx->tx_dir[c] = tx ? 1 : 0;
     }
     return ddc_tune(ctx, channel, phi);
+}
+
+/* ---- the NCO as the kernels evaluate it ----------------------------------- */
+
+int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *sin14, int16_t *cos14)
+{
+    if (!ctx) return -EINVAL;
+    if (count == 0) return 0;
+    if (!sin14 || !cos14) return fail(ctx, -EINVAL, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    int16_t *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, (size_t)count * 2 * sizeof(int16_t)));
+    const uint32_t grid = std::min<uint32_t>((count + 255) / 256, 4096);
+    ddc::ddc_nco_sweep<<<grid, 256, 0, ctx->stream>>>(ctx->d_nco_tab, first_phase, count, d, d + count);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(sin14, d, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cos14, d + count, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, -EIO, std::string("ddc_debug_nco: ") + hipGetErrorString(e));
+    return 0;
 }
 
 /* ---- the constant tables compiled into this library ---------------------- */
