@@ -330,11 +330,13 @@ int ddc_audio_get_status(ddc_ctx *ctx, int32_t channel, ddc_audio_status *out);
  * -2 sc | 2 cc << 16} of the coarse ROMs), "nco_fine_sine" int16[2048] (the kernels'
  * arithmetic form of the fine sine ROM).  out = NULL only reports the size. */
 int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes);
-/* Debug tap: the NCO exactly as the RX / TX kernels evaluate it (coarse table, arithmetic fine
- * sine, angle sums with the rounding of nco_nco_ii_0.v:370-391), for `count` consecutive 22-bit
- * phase-accumulator values from first_phase (wrapping): 14-bit sine and cosine into host arrays.
- * The RX mixer uses these >> 2 (FPGA/nco_shift.v:9), the TX mixer all 14 bits. */
-int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *sin14, int16_t *cos14);
+/* Debug tap: the NCO exactly as the kernels evaluate it (coarse table, arithmetic fine sine,
+ * angle sums with the rounding of nco_nco_ii_0.v:370-391), for `count` consecutive 22-bit
+ * phase-accumulator values from first_phase (wrapping), into host arrays: sin14 / cos14 by the TX
+ * kernel's code (all 14 bits, FPGA/tx_mixer.v), sin12 / cos12 (may be NULL) by the RX kernel's
+ * code (14 bits >> 2, FPGA/nco_shift.v:9). */
+int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *sin14, int16_t *cos14,
+                  int16_t *sin12, int16_t *cos12);
 
 /* Packed-ADC helpers and the synthetic test signal of the benchmark
  * (two tones + uniform noise, xorshift64* seeded 0x5EED0000 + channel). */

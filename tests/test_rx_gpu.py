@@ -498,7 +498,7 @@ def test_nco_of_the_kernels_for_every_phase(ddc, orc):
     """All 2^22 accumulator values through the kernels' NCO (table fetch, float fine sine,
     angle sums) against the ROM arithmetic of nco_nco_ii_0.v:370-391 from the oracle's tables."""
     d = ddc.Ddc(1)
-    s14, c14 = d.debug_nco(0, 1 << 22)
+    s14, c14, s12, c12 = d.debug_nco(0, 1 << 22)
     d.close()
     sc, cc, sf, cf = [t.astype(np.int64) for t in orc.nco_tables()]
     acc = np.arange(1 << 22, dtype=np.int64)
@@ -507,11 +507,13 @@ def test_nco_of_the_kernels_for_every_phase(ddc, orc):
     want_c = np.clip((cc[ic] * cf[ifn] - sc[ic] * sf[ifn] + 4096) >> 13, -8191, 8191)
     assert np.array_equal(s14, want_s), "sine differs at phases %s" % np.nonzero(s14 != want_s)[0][:8]
     assert np.array_equal(c14, want_c), "cosine differs at phases %s" % np.nonzero(c14 != want_c)[0][:8]
+    # the RX kernel's form: the 12-bit mixer operands (nco_shift.v:9)
+    assert np.array_equal(s12, want_s >> 2) and np.array_equal(c12, want_c >> 2)
     # spot values against the oracle's own evaluator, and the wrap of the phase argument
     for a in (0, 1, 2047, 2048, (1 << 21) + 5, (1 << 22) - 1):
         assert (int(s14[a]), int(c14[a])) == tuple(orc.nco_eval(a))
     d = ddc.Ddc(1)
-    s2, c2 = d.debug_nco((1 << 22) - 4, 8)
+    s2, c2, _, _ = d.debug_nco((1 << 22) - 4, 8)
     d.close()
     assert np.array_equal(s2, np.concatenate([s14[-4:], s14[:4]]))
     assert np.array_equal(c2, np.concatenate([c14[-4:], c14[:4]]))

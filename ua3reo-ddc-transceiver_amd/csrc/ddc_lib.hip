@@ -271,18 +271,28 @@ __global__ void ddc_nco_fine_selfcheck(uint32_t *out)
 }
 
 // The kernels' NCO (coarse table in LDS, fine sine, angle sums) evaluated for a run
-// of consecutive 22-bit phases: 14-bit sine and cosine.
+// of consecutive 22-bit phases, in both forms the kernels use: the TX form (14-bit
+// sine and cosine) and the RX form (the 12-bit mixer operands).
 __global__ __launch_bounds__(256) void ddc_nco_sweep(const uint2 *__restrict__ nco_tab, uint32_t first_phase,
-                                                     uint32_t count, int16_t *__restrict__ s14, int16_t *__restrict__ c14)
+                                                     uint32_t count, int16_t *__restrict__ out)
 {
-    __shared__ uint2 tab[2048];
-    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) tab[i] = nco_tab[i];
+    __shared__ uint2 tab[2048], tab2[2048];
+    for (uint32_t i = threadIdx.x; i < 2048; i += blockDim.x) {
+        tab[i] = nco_tab[i];
+        tab2[i] = nco_entry_doubled(nco_tab[i]);
+    }
     __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint32_t acc30 = ((first_phase + i) & 0x3FFFFFu) << 8;
         int s, c;
-        nco14(tab, ((first_phase + i) & 0x3FFFFFu) << 8, s, c);
-        s14[i] = (int16_t)s;
-        c14[i] = (int16_t)c;
+        nco14x(tab2, acc30, s, c);
+        out[i] = (int16_t)(s >> 16);
+        out[count + i] = (int16_t)(c >> 16);
+        // RX: the mixer multiplies the ADC sample by these two and returns the products
+        int pi, pq;
+        nco_mix(tab, acc30, 1, pi, pq);
+        out[2 * (size_t)count + i] = (int16_t)pi;
+        out[3 * (size_t)count + i] = (int16_t)pq;
     }
 }
 
@@ -1586,19 +1596,22 @@ int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
 
 /* ---- the NCO as the kernels evaluate it ----------------------------------- */
 
-int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *sin14, int16_t *cos14)
+int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *sin14, int16_t *cos14,
+                  int16_t *sin12, int16_t *cos12)
 {
     if (!ctx) return -EINVAL;
     if (count == 0) return 0;
     if (!sin14 || !cos14) return fail(ctx, -EINVAL, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     int16_t *d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, (size_t)count * 2 * sizeof(int16_t)));
+    HIP_TRY(ctx, hipMalloc(&d, (size_t)count * 4 * sizeof(int16_t)));
     const uint32_t grid = std::min<uint32_t>((count + 255) / 256, 4096);
-    ddc::ddc_nco_sweep<<<grid, 256, 0, ctx->stream>>>(ctx->d_nco_tab, first_phase, count, d, d + count);
+    ddc::ddc_nco_sweep<<<grid, 256, 0, ctx->stream>>>(ctx->d_nco_tab, first_phase, count, d);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(sin14, d, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(cos14, d + count, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream);
+    int16_t *dst[4] = { sin14, cos14, sin12, cos12 };
+    for (int k = 0; k < 4 && e == hipSuccess; k++)
+        if (dst[k])
+            e = hipMemcpyAsync(dst[k], d + (size_t)k * count, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, -EIO, std::string("ddc_debug_nco: ") + hipGetErrorString(e));

@@ -63,14 +63,24 @@ __global__ void ddc_tx_ciccomp(const int16_t *__restrict__ iq48k, const int16_t 
     y[1] = (uint32_t)(uint16_t)cround32(a2i, 14, 30) | ((uint32_t)(uint16_t)cround32(a2q, 14, 30) << 16);
 }
 
-// 14-bit NCO outputs for one phase (no saturation can occur: see tests)
-__device__ __forceinline__ void nco14(const uint2 *tab, uint32_t acc32, int &s14, int &c14)
+// 14-bit NCO outputs for one phase (no saturation can occur: see tests).  tab2 holds
+// the coarse entries doubled ({4 cc | 4 sc << 16, -4 sc | 4 cc << 16}, still 16-bit) and the
+// {fine sine, 8191} operand is doubled too, so the angle sums come out times four
+// and the 14-bit values sit in the upper halves, where a multiply selects them for
+// free; s14 / c14 are returned in that form (value << 16 plus rounding remainder).
+__device__ __forceinline__ void nco14x(const uint2 *tab2, uint32_t acc30, int &s14x, int &c14x)
 {
     uint2 e;
     uint32_t w;
-    nco_fetch(tab, acc32, e, w);
-    s14 = dot2_sconst(e.x, w, 8192) >> 14;
-    c14 = dot2_sconst(e.y, w, 8192) >> 14;
+    nco_fetch(tab2, acc30, e, w);
+    w += w;
+    s14x = dot2_sconst(e.x, w, 32768);
+    c14x = dot2_sconst(e.y, w, 32768);
+}
+__device__ __forceinline__ uint2 nco_entry_doubled(uint2 e)
+{
+    // each 16-bit half doubled (|2 cc|, |2 sc| <= 16382)
+    return make_uint2(((e.x & 0x7FFF7FFFu) << 1), ((e.y & 0x7FFF7FFFu) << 1));
 }
 
 // Running-sum walk of the interpolated tx_cic output over one segment,
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
     __shared__ uint2 tab[2048];
     __shared__ uint4 obuf[8 * 256];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave_base = tid & ~63u;
-    for (uint32_t i = tid; i < 2048; i += blockDim.x) tab[i] = nco_tab[i];
+    for (uint32_t i = tid; i < 2048; i += blockDim.x) tab[i] = nco_entry_doubled(nco_tab[i]);
 
     // flush targets: store j of a wave covers rows wave_base + 8 j .. + 7, lane l
     // writing, for row 8 j + (l >> 3), the piece held in slot l & 7; offsets in
@@ -233,9 +243,9 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
             uint32_t sum[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                int s14, c14;
-                nco14(tab, h ? (uint32_t)(php >> 32) : (uint32_t)php, s14, c14);
-                sum[h] = (uint32_t)(__mul24(wi.out14(), s14) + __mul24(wq.out14(), c14) + (8191 << 14));
+                int s14x, c14x;
+                nco14x(tab, h ? (uint32_t)(php >> 32) : (uint32_t)php, s14x, c14x);
+                sum[h] = (uint32_t)(__mul24(wi.out14(), s14x >> 16) + __mul24(wq.out14(), c14x >> 16) + (8191 << 14));
                 wi.next();
                 wq.next();
             }

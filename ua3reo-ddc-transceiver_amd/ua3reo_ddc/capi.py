@@ -100,7 +100,7 @@ def lib():
     L.ddc_set_params.argtypes = [vp, i32, vp]
     L.ddc_pack_adc12.argtypes = [vp, sz, vp]
     L.ddc_debug_table.argtypes = [C.c_char_p, vp, sz, C.POINTER(sz)]
-    L.ddc_debug_nco.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
+    L.ddc_debug_nco.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.ddc_synth_adc_dev.argtypes = [u32, u32, u32, sz, vp, sz, vp]
     L.ddc_pack_adc12.restype = None
     L.ddc_unpack_adc12.argtypes = [vp, sz, vp]
@@ -278,11 +278,11 @@ class Ddc:
         self._check(self._L.ddc_rx_process_dev_static(self._h, adc_ptr, row_bytes, samples, spec_ptr, voice_ptr))
 
     def debug_nco(self, first_phase, count):
-        """(sin14, cos14) of the kernels' NCO for `count` consecutive 22-bit phases (int16 arrays)."""
-        s = np.zeros(count, np.int16)
-        c = np.zeros(count, np.int16)
-        self._check(self._L.ddc_debug_nco(self._h, first_phase, count, _np_ptr(s), _np_ptr(c)))
-        return s, c
+        """(sin14, cos14, sin12, cos12) of the kernels' NCO for `count` consecutive 22-bit phases:
+        the TX kernel's 14-bit values and the RX kernel's 12-bit mixer operands (int16 arrays)."""
+        out = [np.zeros(count, np.int16) for _ in range(4)]
+        self._check(self._L.ddc_debug_nco(self._h, first_phase, count, *[_np_ptr(a) for a in out]))
+        return tuple(out)
 
     def rx_read_cic(self, samples):
         out = np.zeros((self.n_channels, samples // 512, 2), np.int16)
