@@ -17,7 +17,7 @@
  * channels parallelise over both.
  *
  * Kernel 1 (ddc_rx_front) is the only one that touches the ADC stream; it is
- * bound by vector-ALU issue (about 20 integer lane-ops per sample), reads every
+ * bound by vector-ALU issue (about 18 vector instructions per sample), reads every
  * ADC byte once (1.5 B per sample) and writes 80 B of moments per 512 samples.
  */
 #pragma once
