@@ -133,3 +133,22 @@ def test_tx_full_size_properties(ddc, orc):
     for c in (0, 100, 254):
         want = orc.TxChain(phis[c]).run(iq[c, :8].cpu().numpy())
         assert np.array_equal(a[c, :8192].cpu().numpy().view(np.uint16), want)
+
+
+def test_tx_compensator_output_held_at_the_rails(ddc, orc):
+    """Constant inputs of -31232 / -31233 hold both tx_ciccomp phases at -32768 / +32767
+    (gain and wrap of the Q14 taps), which drives the tx_cic polynomial to its extremes:
+    -2^51 exactly, the smallest start value the integer walk has to represent."""
+    n = 40  # the 24-tap phases settle after 24 inputs
+    vals = [(-31232, -31232), (-31233, -31233), (-31232, -31233), (31232, 31231)]
+    iq = np.stack([np.stack([np.full(n, a), np.full(n, b)], axis=1) for a, b in vals]).astype(np.int16)
+    held = orc.TxCicComp().run(iq[0, :, 0].copy())
+    assert np.all(held[-8:] == -32768)
+    assert np.all(orc.TxCicComp().run(iq[1, :, 0].copy())[-8:] == 32767)
+    phis = [605867, 1, 0x200000, 3 << 20]
+    d = ddc.Ddc(len(vals))
+    d.tune_many(phis)
+    dac = d.tx_process(iq)
+    d.close()
+    for c in range(len(vals)):
+        assert np.array_equal(dac[c], orc.TxChain(phis[c]).run(iq[c])), "channel %d" % c
