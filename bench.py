@@ -65,6 +65,7 @@ def parse_args(argv=None):
                          "--samples 4194304)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-copy-rate", action="store_true", help="skip the device-to-device copy rate in the roofline block")
     ap.add_argument("--shared-stream", action="store_true",
                     help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
                          "reported apart from the headline: the ADC bytes then come from L2, not HBM")
@@ -203,6 +204,28 @@ def dry_run(args, rank, world):
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def measured_copy_gbs(torch, dev):
+    """Device-to-device copy rate of this GPU (read + write bytes per second), the practical
+    HBM figure next to the 8 TB/s of the data sheet: best of 5 copies of 1 GiB after a warm-up."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    src.zero_()
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del src, dst
+    return 2.0 * n / (best * 1e-3) / 1e9
 
 
 def main(argv=None):
@@ -374,6 +397,11 @@ def main(argv=None):
             "rest_of_call_ms": round(tail_ms / max(1, ncalls), 4),
             "algorithmic_bytes_per_launch": BYTES_PER_CHANNEL_SAMPLE * nch * S,
         }
+        if not args.no_copy_rate:
+            copy_gbs = measured_copy_gbs(torch, dev)
+            roof["measured_d2d_copy"] = {"gbs": round(copy_gbs, 1), "frac_of_it": round(achieved / copy_gbs, 4),
+                                         "what": "torch copy of 1 GiB on this GPU after the timed region, read + write "
+                                                 "bytes / best of 5; `frac` above stays against the 8000 GB/s peak"}
         if valu:
             # vector-ALU issue roof: instruction counts of the PMC pass priced with the probe's issue
             # cycles per instruction class, against the SIMD cycles of this run's launches
