@@ -460,6 +460,8 @@ def main(argv=None):
                 "channels_per_gpu": nch,
                 "samples_per_channel": S,
                 "fs_adc_hz": FS_ADC,
+                "per_stream_msps": round(value / (world * nch), 1),
+                "per_stream_times_real_time": round(value * 1e6 / (world * nch) / FS_ADC, 1),
                 "parallelism": "channels sharded over %d GPU(s)%s" % (
                     world, ", RCCL all-gather of decimated I/Q each step, overlapped with the next step"
                     if do_gather else ""),
