@@ -69,6 +69,9 @@ def parse_args(argv=None):
     ap.add_argument("--shared-stream", action="store_true",
                     help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
                          "reported apart from the headline: the ADC bytes then come from L2, not HBM")
+    ap.add_argument("--rx-plan", choices=["auto", "split"], default="auto",
+                    help="auto: the library picks the RX call plan by size (one kernel for the bench shapes); "
+                         "split: the separate kernels, for A/B timing on one box")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU)")
     ap.add_argument("--dry-run-gloo", action="store_true",
@@ -284,6 +287,8 @@ def main(argv=None):
     phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * (chan0 + c))[0] for c in range(nch)]
     ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
     ctx.tune_many(phis)
+    if args.rx_plan == "split":
+        ctx.debug_rx_plan(1)
     fft_params = dict(mode="USB", fft_averaging=4)
     if with_fft:
         ctx.audio_configure(ua3reo_ddc.audio_params(**fft_params))

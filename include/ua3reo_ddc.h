@@ -107,8 +107,16 @@ int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_byt
 size_t ddc_rx_static_scratch_bytes(void);
 size_t ddc_rx_static_scratch_need(uint32_t n_channels, size_t samples);
 /* Debug tap: the raw rx_cic outputs of the last ddc_rx_process* call,
- * [channel][samples/512][2] int16 (host pointer). */
+ * [channel][samples/512][2] int16 (host pointer).  After ddc_rx_process_dev_static
+ * the outputs sit in the GPU's shared work area: read them before another ctx makes
+ * a static call on that GPU. */
 int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples);
+/* Debug switch.  An RX call whose samples / 512 is a multiple of 256 runs as one
+ * kernel, any other size as six smaller kernels; the results are the same bit for
+ * bit and the carried state is common, so calls of both kinds may alternate.
+ * plan = 1 makes every call of this ctx use the separate kernels (for A/B timing
+ * and for tests), plan = 0 restores the choice by size. */
+int ddc_debug_rx_plan(ddc_ctx *ctx, int plan);
 
 /* TX: 48 kHz I/Q -> DAC words at 1024x the rate.
  * Replaces the FPGA TX datapath tx_ciccomp.vhd + tx_cic.vhd + tx_mixer.v +

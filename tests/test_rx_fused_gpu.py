@@ -1,0 +1,120 @@
+"""The two-kernel RX call plan (sample counts whose 512-sample block count is a multiple of
+256: rx_cic outputs formed inside the ingest kernel, one tail kernel for the 48 kHz stages
+and the state hand-over) against the oracle and against the six-kernel plan of the same
+library: every output bit-exact, for single short tiles, several tiles with a partial last
+one, calls of both plans alternating on one stream of samples, many channels at once, and
+the raw rx_cic tap."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BLK = 512 * 256  # samples of one workgroup's 256 windows
+
+
+@pytest.fixture(scope="module")
+def ddc():
+    import ua3reo_ddc
+    ua3reo_ddc.lib()
+    return ua3reo_ddc
+
+
+def rows_of(ddc, chans):
+    return np.stack([ddc.pack_adc12(x) for x in chans])
+
+
+@pytest.mark.parametrize("n_wg", [1, 2, 7, 8, 9, 17])
+def test_two_kernel_call_equals_oracle_and_split_plan(ddc, orc, n_wg):
+    """n_wg workgroups per channel: 1 / 2 / 7 (a short tile), 8 (one full tile), 9 and 17
+    (tiles that reach back into the previous one, the last tile partial)."""
+    n = n_wg * BLK
+    nch = 3
+    rng = np.random.default_rng(100 + n_wg)
+    chans = [rng.integers(-2048, 2048, n).astype(np.int16) for _ in range(nch)]
+    chans[1][1000:3000] = -2048
+    phis = [605867, 3 << 20, 4194303]
+    rows = rows_of(ddc, chans)
+    d = ddc.Ddc(nch)
+    d.tune_many(phis)
+    spec, voice = d.rx_process(rows, n)
+    cic = d.rx_read_cic(n)
+    e = ddc.Ddc(nch)
+    e.tune_many(phis)
+    e.debug_rx_plan(1)
+    spec2, voice2 = e.rx_process(rows, n)
+    cic2 = e.rx_read_cic(n)
+    assert np.array_equal(cic, cic2)
+    assert np.array_equal(spec, spec2) and np.array_equal(voice, voice2)
+    for c in range(nch):
+        ws, wv, wc = orc.RxChain(phis[c]).run(chans[c], want_cic=True)
+        assert np.array_equal(cic[c], wc), c
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+    # a second call of each carries on from the first's state
+    more = [rng.integers(-2048, 2048, BLK).astype(np.int16) for _ in range(nch)]
+    s3, v3 = d.rx_process(rows_of(ddc, more), BLK)
+    s4, v4 = e.rx_process(rows_of(ddc, more), BLK)
+    assert np.array_equal(s3, s4) and np.array_equal(v3, v4)
+    for c in range(nch):
+        assert d.rx_get_phase(c) == e.rx_get_phase(c) == (phis[c] * (n + BLK)) & 0x3FFFFF
+    d.close()
+    e.close()
+
+
+@pytest.mark.parametrize("sizes", [[BLK, 1024, 2 * BLK, 3072, BLK], [9 * BLK, BLK, 1024 * 5, 8 * BLK],
+                                   [1024, BLK, BLK, BLK]])
+def test_both_plans_alternate_on_one_stream_of_samples(ddc, orc, sizes):
+    total = sum(sizes)
+    nch = 2
+    rng = np.random.default_rng(len(sizes) + sizes[0])
+    chans = [rng.integers(-2048, 2048, total).astype(np.int16) for _ in range(nch)]
+    phis = [85333, 1234567]
+    d = ddc.Ddc(nch)
+    d.tune_many(phis)
+    specs, voices, pos = [], [], 0
+    for s in sizes:
+        sp, vo = d.rx_process(rows_of(ddc, [c[pos:pos + s] for c in chans]), s)
+        specs.append(sp)
+        voices.append(vo)
+        pos += s
+    d.close()
+    spec, voice = np.concatenate(specs, axis=1), np.concatenate(voices, axis=1)
+    for c in range(nch):
+        ws, wv = orc.RxChain(phis[c]).run(chans[c])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+
+
+def test_many_channels_two_tiles_each_three_calls(ddc, orc):
+    """700 channels x 9 workgroups (two tiles per channel, so the arrival counter of the tail
+    kernel decides which workgroup saves a channel's state), more workgroups than the GPU holds
+    at once, three calls into the same buffers (outputs and work buffers of earlier calls in the
+    caches).  Against the six-kernel plan on every channel and the oracle on a few."""
+    torch = pytest.importorskip("torch")
+    nch, n = 700, 9 * BLK
+    rb = n // 2 * 3
+    nf = n // 1024
+    phis = [(977 * c + 605867) % (1 << 22) for c in range(nch)]
+    a = ddc.Ddc(nch)
+    b = ddc.Ddc(nch)
+    a.tune_many(phis)
+    b.tune_many(phis)
+    b.debug_rx_plan(1)
+    g = torch.Generator(device="cuda").manual_seed(2026)
+    out_a = torch.zeros((2, nch, nf, 2), dtype=torch.int16, device="cuda")
+    out_b = torch.zeros_like(out_a)
+    keep = []
+    for k in range(3):
+        adc = torch.randint(0, 256, (nch, rb), dtype=torch.uint8, device="cuda", generator=g)
+        torch.cuda.synchronize()
+        a.rx_process_dev(adc.data_ptr(), rb, n, out_a[0].data_ptr(), out_a[1].data_ptr())
+        b.rx_process_dev(adc.data_ptr(), rb, n, out_b[0].data_ptr(), out_b[1].data_ptr())
+        a.sync()
+        b.sync()
+        assert torch.equal(out_a, out_b), "call %d: the two call plans differ" % k
+        keep.append((adc[[0, 350, 699]].cpu().numpy(), out_a[:, [0, 350, 699]].cpu().numpy()))
+    for i, c in enumerate((0, 350, 699)):
+        x = np.concatenate([ddc.unpack_adc12(h[i], n) for h, _ in keep])
+        ws, wv = orc.RxChain(phis[c]).run(x)
+        assert np.array_equal(np.concatenate([o[0, i] for _, o in keep]), ws), c
+        assert np.array_equal(np.concatenate([o[1, i] for _, o in keep]), wv), c
+    a.close()
+    b.close()

@@ -61,11 +61,42 @@ def test_static_work_area_matches_growing_buffers(ddc, orc):
 def test_static_work_area_rejects_oversized_calls(ddc):
     torch = pytest.importorskip("torch")
     L = ddc.lib()
-    n_ch, n = 1024, 1 << 20                  # the bench shape: 176 MB of work buffers
-    assert L.ddc_rx_static_scratch_need(n_ch, n) > L.ddc_rx_static_scratch_bytes()
+    # 1024 channels x 2^20 samples (the bench shape) runs as one kernel and fits (about 15 MB);
+    # the same samples plus 1024 go the separate-kernel way, whose window moments alone are 176 MB
+    n_ch, n = 1024, 1 << 20
+    assert L.ddc_rx_static_scratch_need(n_ch, n) <= L.ddc_rx_static_scratch_bytes()
+    assert L.ddc_rx_static_scratch_need(n_ch, n + 1024) > L.ddc_rx_static_scratch_bytes()
+    assert L.ddc_rx_static_scratch_need(n_ch, 4 * n) > L.ddc_rx_static_scratch_bytes()
     d = ddc.Ddc(n_ch)
     adc = torch.zeros((16,), dtype=torch.uint8, device="cuda")   # never read: the call must refuse first
     out = torch.zeros((16,), dtype=torch.int16, device="cuda")
-    with pytest.raises(ddc.DdcError, match="work area"):
-        d.rx_process_dev_static(adc.data_ptr(), n // 2 * 3, n, out.data_ptr(), out.data_ptr())
+    for samples in (n + 1024, 4 * n):
+        with pytest.raises(ddc.DdcError, match="work area"):
+            d.rx_process_dev_static(adc.data_ptr(), samples // 2 * 3, samples, out.data_ptr(), out.data_ptr())
     d.close()
+
+
+def test_static_work_area_runs_the_bench_shape(ddc, orc):
+    """1024 channels x 2^20 samples through the entry point that allocates nothing, twice, against
+    ddc_rx_process_dev on a second ctx; then a smaller call of each."""
+    torch = pytest.importorskip("torch")
+    n_ch, n = 1024, 1 << 20
+    rb = n // 2 * 3
+    phis = [(977 * c + 605867) % (1 << 22) for c in range(n_ch)]
+    ref, stat = ddc.Ddc(n_ch), ddc.Ddc(n_ch)
+    ref.tune_many(phis)
+    stat.tune_many(phis)
+    g = torch.Generator(device="cuda").manual_seed(31)
+    for samples in (n, n, 1 << 17):
+        adc = torch.randint(0, 256, (n_ch, samples // 2 * 3), dtype=torch.uint8, device="cuda", generator=g)
+        nf = samples // 1024
+        out_ref = torch.zeros((2, n_ch, nf, 2), dtype=torch.int16, device="cuda")
+        out_st = torch.full((2, n_ch, nf, 2), 0x5A5A, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        ref.rx_process_dev(adc.data_ptr(), samples // 2 * 3, samples, out_ref[0].data_ptr(), out_ref[1].data_ptr())
+        stat.rx_process_dev_static(adc.data_ptr(), samples // 2 * 3, samples, out_st[0].data_ptr(), out_st[1].data_ptr())
+        ref.sync()
+        stat.sync()
+        assert torch.equal(out_ref, out_st)
+    ref.close()
+    stat.close()

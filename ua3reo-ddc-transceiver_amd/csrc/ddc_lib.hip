@@ -37,6 +37,14 @@ struct ddc_ctx {
     unsigned long long *d_mom = nullptr;
     int16_t *d_cic = nullptr;
     int16_t *d_comp = nullptr;
+    // work buffers of the two-kernel call plan (block counts that are a multiple of 256)
+    uint32_t cap_fused_blk = 0;
+    int16_t *d_cicf = nullptr;           // rx_cic outputs
+    unsigned long long *d_edge = nullptr; // workgroup-edge moment records
+    uint32_t *d_cnt = nullptr;            // arrival counters, zero between calls
+    uint32_t *d_comp_tail = nullptr;      // last 256 compensator outputs of a call, on their way into the history
+    size_t cnt_words = 0;
+    int rx_plan = 0;                      // 0: by shape; 1: always the separate kernels (ddc_debug_rx_plan)
     // history saved between calls (layout independent of the call size)
     unsigned long long *d_hist_mom = nullptr; // [ch][5][10]
     int16_t *d_hist_cic = nullptr;            // [ch][64][2]
@@ -136,10 +144,49 @@ int ensure_capacity(ddc_ctx *ctx, uint32_t n_blk)
     if (ctx->d_cic) (void)hipFree(ctx->d_cic);
     if (ctx->d_comp) (void)hipFree(ctx->d_comp);
     ctx->d_mom = nullptr; ctx->d_cic = nullptr; ctx->d_comp = nullptr; ctx->cap_blk = 0;
+    ctx->last_cic = nullptr; ctx->last_blk = 0; // the debug tap must not read a freed buffer if the call fails later
     HIP_TRY(ctx, hipMalloc(&ctx->d_mom, nch * (ddc::kMomHist + (size_t)n_blk) * 10 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_cic, nch * (ddc::kCicHist + (size_t)n_blk) * 2 * sizeof(int16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_comp, nch * (ddc::kCompHist + (size_t)n_blk / 2) * 2 * sizeof(int16_t)));
     ctx->cap_blk = n_blk;
+    return 0;
+}
+
+// Work buffers of the two-kernel call plan for n_blk blocks per channel (n_blk a multiple of 256).
+struct FusedLayout { size_t cic, edge, tail, cnt_words, n_wg, n_tiles; };
+FusedLayout fused_layout(size_t nch, size_t n_blk)
+{
+    FusedLayout f;
+    f.n_wg = n_blk / ddc::kFrontThreads;
+    f.n_tiles = (n_blk / 2 + ddc::kTailTile - 1) / ddc::kTailTile;
+    f.cic = nch * (ddc::kCicHist + n_blk) * 2 * sizeof(int16_t);
+    f.edge = nch * f.n_wg * ddc::kEdgeRecs * 10 * sizeof(unsigned long long);
+    f.tail = nch * ddc::kCompHist * 2 * sizeof(int16_t);
+    f.cnt_words = nch;
+    return f;
+}
+
+int ensure_fused_capacity(ddc_ctx *ctx, uint32_t n_blk)
+{
+    if (n_blk <= ctx->cap_fused_blk) return 0;
+    const FusedLayout f = fused_layout(ctx->cfg.n_channels, n_blk);
+    if (ctx->d_cicf) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_cicf) (void)hipFree(ctx->d_cicf);
+    if (ctx->d_edge) (void)hipFree(ctx->d_edge);
+    if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
+    if (ctx->d_comp_tail) (void)hipFree(ctx->d_comp_tail);
+    ctx->d_comp_tail = nullptr;
+    ctx->d_cicf = nullptr; ctx->d_edge = nullptr; ctx->d_cnt = nullptr; ctx->cap_fused_blk = 0; ctx->cnt_words = 0;
+    ctx->last_cic = nullptr; ctx->last_blk = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_cicf, f.cic));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_edge, f.edge));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_comp_tail, f.tail));
+    // the counters of a smaller call sit at other offsets: every word a call may use starts at zero
+    // and every call leaves its own at zero
+    HIP_TRY(ctx, hipMalloc(&ctx->d_cnt, (f.cnt_words + 3) / 4 * 16));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_cnt, 0, (f.cnt_words + 3) / 4 * 16, ctx->stream));
+    ctx->cnt_words = f.cnt_words;
+    ctx->cap_fused_blk = n_blk;
     return 0;
 }
 
@@ -212,18 +259,36 @@ void device_tables_mark_ready(int device)
     if (device >= 0 && device < kMaxDevices) g_tables_ready[device] = true;
 }
 
-// Byte offsets of the three work buffers inside one area, each 256-byte aligned.
-struct WorkLayout { size_t mom, cic, comp, total; };
-WorkLayout work_layout(size_t nch, size_t n_blk)
+// Byte offsets of the work buffers of one call inside the static area, each 256-byte aligned.
+// The area starts with the arrival counters of the two-kernel plan: they are zero between
+// calls whatever plan or shape the calls before had, because nothing else is ever put there.
+constexpr size_t kStaticCntBytes = 256u << 10;
+struct WorkLayout { bool fused; size_t mom, cic, comp, edge, tail, cnt_words, total; };
+bool plan_is_fused(int rx_plan, size_t n_blk) { return rx_plan == 0 && n_blk % ddc::kFrontThreads == 0; }
+WorkLayout work_layout(size_t nch, size_t n_blk, bool fused)
 {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    WorkLayout w;
-    w.mom = 0;
-    w.cic = up(nch * (ddc::kMomHist + n_blk) * 10 * sizeof(unsigned long long));
+    WorkLayout w{};
+    w.fused = fused;
+    if (fused) {
+        const FusedLayout f = fused_layout(nch, n_blk);
+        w.cnt_words = f.cnt_words;
+        w.cic = kStaticCntBytes;
+        w.edge = w.cic + up(f.cic);
+        w.tail = w.edge + up(f.edge);
+        w.total = w.tail + up(f.tail);
+        if (f.cnt_words * 4 > kStaticCntBytes) w.total = (size_t)-1; // more counters than the reserved block holds
+        return w;
+    }
+    w.mom = kStaticCntBytes;
+    w.cic = w.mom + up(nch * (ddc::kMomHist + n_blk) * 10 * sizeof(unsigned long long));
     w.comp = w.cic + up(nch * (ddc::kCicHist + n_blk) * 2 * sizeof(int16_t));
     w.total = w.comp + up(nch * (ddc::kCompHist + n_blk / 2) * 2 * sizeof(int16_t));
     return w;
 }
+
+// Device buffers one RX call works in (ctx-owned or carved from the static area).
+struct RxWork { unsigned long long *mom; int16_t *cic; int16_t *comp; unsigned long long *edge; uint32_t *tail; uint32_t *cnt; };
 } // namespace
 
 namespace ddc {
@@ -498,7 +563,7 @@ void ddc_destroy(ddc_ctx *ctx)
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
                      ctx->d_out, ctx->d_tx_xs, ctx->d_fft_rows, ctx->d_wtf, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
-                     ctx->d_stage[2] };
+                     ctx->d_stage[2], ctx->d_cicf, ctx->d_edge, ctx->d_cnt, ctx->d_comp_tail };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     ddc_tx_state_destroy(&ctx->tx);
@@ -579,6 +644,7 @@ int ddc_rx_reset(ddc_ctx *ctx, int32_t channel)
                                 n * ddc::kMomHist * 10 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_cic + lo * ddc::kCicHist * 2, 0, n * ddc::kCicHist * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_comp + lo * ddc::kCompHist * 2, 0, n * ddc::kCompHist * 4, ctx->stream));
+    if (channel < 0 && ctx->d_cnt) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cnt, 0, (ctx->cnt_words + 3) / 4 * 16, ctx->stream));
     return 0;
 }
 
@@ -627,28 +693,50 @@ static int rx_check_args(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, s
 
 // Queues one RX call on the ctx stream with the given work buffers.  pev: three
 // events to record around the ingest kernel and the rest, or null.
+//
+// Two call plans, same arithmetic: block counts that are a multiple of 256 run as two
+// kernels (ddc_rx_front_cic: a workgroup owns 256 windows of one channel and combines them
+// into rx_cic outputs itself; ddc_rx_tail: the 48 kHz stages and the state hand-over, one
+// workgroup per 1024 frames); any other block count runs the six separate kernels.
 static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples, uint32_t n_blk,
-                     int16_t *spec_iq, int16_t *voice_iq, unsigned long long *mom, int16_t *cic, int16_t *comp,
-                     hipEvent_t *pev)
+                     int16_t *spec_iq, int16_t *voice_iq, bool fused, const RxWork &w, hipEvent_t *pev)
 {
     const uint32_t nch = ctx->cfg.n_channels, total = n_blk * nch, nf = n_blk / 2;
     hipStream_t st = ctx->stream;
-    ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, mom, cic, comp,
-                                                 n_blk, ctx->d_carry[0], ctx->d_carry[1]);
-    const uint32_t *cin = ctx->d_carry[1];
-    uint32_t *cout = ctx->d_carry[0];
-    if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
-    ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
-        adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, mom, ctx->d_nco_tab);
-    if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
-    const uint32_t ctiles = (n_blk + 255) / 256;
-    ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(mom, n_blk, ctiles, cic);
-    const uint32_t tiles = (nf + ddc::kTailTile - 1) / ddc::kTailTile;
-    ddc::ddc_rx_ciccomp<<<nch * tiles, 256, 0, st>>>(cic, n_blk, tiles, comp, spec_iq);
-    ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(comp, nf, tiles, voice_iq);
-    ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, mom, cic, comp,
-                                                 ctx->d_acc, ctx->d_phi, n_blk, (uint32_t)samples);
-    if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
+    if (fused) {
+        ddc::RxFused fa{};
+        const FusedLayout f = fused_layout(nch, n_blk);
+        fa.cic = w.cic; fa.edge = w.edge; fa.comp_tail = w.tail;
+        fa.chan_cnt = w.cnt;
+        fa.hist_mom = ctx->d_hist_mom; fa.hist_cic = ctx->d_hist_cic; fa.hist_comp = ctx->d_hist_comp;
+        fa.carry_saved = ctx->d_carry[0]; fa.carry_work = ctx->d_carry[1]; fa.acc0 = ctx->d_acc;
+        fa.phi32v = ctx->d_phi;
+        fa.spec_iq = spec_iq; fa.voice_iq = voice_iq;
+        fa.n_wg = (uint32_t)f.n_wg; fa.n_tiles = (uint32_t)f.n_tiles; fa.samples_lo = (uint32_t)samples;
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
+        ddc::ddc_rx_front_cic<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, total,
+                                                                                       ctx->d_phi, ctx->d_nco_tab, fa);
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
+        ddc::ddc_rx_tail<<<nch * fa.n_tiles, 256, 0, st>>>(n_blk, fa);
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
+    } else {
+        ddc::ddc_rx_load_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, w.mom, w.cic,
+                                                     w.comp, n_blk, ctx->d_carry[0], ctx->d_carry[1]);
+        const uint32_t *cin = ctx->d_carry[1];
+        uint32_t *cout = ctx->d_carry[0];
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
+        ddc::ddc_rx_front<<<(total + ddc::kFrontThreads - 1) / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(
+            adc12, row_bytes, n_blk, total, ctx->d_acc, ctx->d_phi, cin, cout, w.mom, ctx->d_nco_tab);
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
+        const uint32_t ctiles = (n_blk + 255) / 256;
+        ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(w.mom, n_blk, ctiles, w.cic);
+        const uint32_t tiles = (nf + ddc::kTailTile - 1) / ddc::kTailTile;
+        ddc::ddc_rx_ciccomp<<<nch * tiles, 256, 0, st>>>(w.cic, n_blk, tiles, w.comp, spec_iq);
+        ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(w.comp, nf, tiles, voice_iq);
+        ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, w.mom, w.cic,
+                                                     w.comp, ctx->d_acc, ctx->d_phi, n_blk, (uint32_t)samples);
+        if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
+    }
     if (ctx->adc_stats) {
         const uint32_t pieces = (uint32_t)(samples / 32);
         const uint32_t gx = std::min<uint32_t>((pieces + 255) / 256, std::max<uint32_t>(1, 4096 / nch));
@@ -668,7 +756,8 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     int rc = rx_check_args(ctx, adc12, row_bytes, samples, spec_iq, voice_iq, &n_blk);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    rc = ensure_capacity(ctx, n_blk);
+    const bool fused = plan_is_fused(ctx->rx_plan, n_blk);
+    rc = fused ? ensure_fused_capacity(ctx, n_blk) : ensure_capacity(ctx, n_blk);
     if (rc) return rc;
     hipEvent_t *pev = nullptr;
     if (ctx->profile) {
@@ -678,10 +767,12 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
         ctx->prof_head = (ctx->prof_head + 1) % ddc_ctx::kProfRing;
         if (ctx->prof_count < ddc_ctx::kProfRing) ctx->prof_count++;
     }
-    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq, ctx->d_mom, ctx->d_cic, ctx->d_comp, pev);
+    const RxWork w = fused ? RxWork{ nullptr, ctx->d_cicf, nullptr, ctx->d_edge, ctx->d_comp_tail, ctx->d_cnt }
+                           : RxWork{ ctx->d_mom, ctx->d_cic, ctx->d_comp, nullptr, nullptr, nullptr };
+    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq, fused, w, pev);
     if (rc) return rc;
     ctx->last_blk = n_blk;
-    ctx->last_cic = ctx->d_cic;
+    ctx->last_cic = w.cic;
     return 0;
 }
 
@@ -689,7 +780,7 @@ size_t ddc_rx_static_scratch_bytes(void) { return DDC_STATIC_SCRATCH_BYTES; }
 
 size_t ddc_rx_static_scratch_need(uint32_t n_channels, size_t samples)
 {
-    return work_layout(n_channels, samples / 512).total;
+    return work_layout(n_channels, samples / 512, plan_is_fused(0, samples / 512)).total;
 }
 
 int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
@@ -700,22 +791,41 @@ int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_byt
     uint32_t n_blk = 0;
     int rc = rx_check_args(ctx, adc12, row_bytes, samples, spec_iq, voice_iq, &n_blk);
     if (rc) return rc;
-    const WorkLayout w = work_layout(ctx->cfg.n_channels, n_blk);
+    const bool fused = plan_is_fused(ctx->rx_plan, n_blk);
+    const WorkLayout w = work_layout(ctx->cfg.n_channels, n_blk, fused);
     if (w.total > DDC_STATIC_SCRATCH_BYTES) {
         char msg[200];
-        snprintf(msg, sizeof msg, "ddc_rx_process_dev_static: %u channels x %zu samples need %zu bytes of work area, "
-                 "the static one holds %u", ctx->cfg.n_channels, samples, w.total, DDC_STATIC_SCRATCH_BYTES);
+        if (w.total == (size_t)-1)
+            snprintf(msg, sizeof msg, "ddc_rx_process_dev_static: %u channels x %zu samples need more arrival counters "
+                     "than the static work area reserves (%zu bytes)", ctx->cfg.n_channels, samples, kStaticCntBytes);
+        else
+            snprintf(msg, sizeof msg, "ddc_rx_process_dev_static: %u channels x %zu samples need %zu bytes of work area, "
+                     "the static one holds %u", ctx->cfg.n_channels, samples, w.total, DDC_STATIC_SCRATCH_BYTES);
         return fail(ctx, -E2BIG, msg);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     unsigned char *base = ctx->scratch_base; // resolved by ddc_create on this ctx's device
     if (!base) return fail(ctx, -EFAULT, "static work area was not resolved when the ctx was created");
-    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq,
-                   reinterpret_cast<unsigned long long *>(base + w.mom), reinterpret_cast<int16_t *>(base + w.cic),
-                   reinterpret_cast<int16_t *>(base + w.comp), nullptr);
+    const RxWork rw = fused ? RxWork{ nullptr, reinterpret_cast<int16_t *>(base + w.cic), nullptr,
+                                      reinterpret_cast<unsigned long long *>(base + w.edge),
+                                      reinterpret_cast<uint32_t *>(base + w.tail), reinterpret_cast<uint32_t *>(base) }
+                            : RxWork{ reinterpret_cast<unsigned long long *>(base + w.mom),
+                                      reinterpret_cast<int16_t *>(base + w.cic),
+                                      reinterpret_cast<int16_t *>(base + w.comp), nullptr, nullptr, nullptr };
+    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq, fused, rw, nullptr);
     if (rc) return rc;
     ctx->last_blk = n_blk;
-    ctx->last_cic = reinterpret_cast<int16_t *>(base + w.cic);
+    ctx->last_cic = rw.cic;
+    return 0;
+}
+
+/* Debug switch: plan 0 picks the call plan by shape (two kernels when samples / 512 is a
+ * multiple of 256), plan 1 always runs the separate kernels.  Same results either way. */
+int ddc_debug_rx_plan(ddc_ctx *ctx, int plan)
+{
+    if (!ctx) return -EINVAL;
+    if (plan != 0 && plan != 1) return fail(ctx, -EINVAL, "ddc_debug_rx_plan: plan is 0 or 1");
+    ctx->rx_plan = plan;
     return 0;
 }
 

@@ -339,6 +339,445 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
     }
 }
 
+// COEF[j][e] * b mod 2^64 with the constant split into sign, an odd factor below
+// 2^32 and a power of two: a 32 x 64 bit product and a shift instead of a full
+// 64 x 64 bit multiply (the small odd factors fold into shifts and adds).
+__host__ __device__ constexpr unsigned long long coef_abs(int j, int e)
+{
+    return COEF[j][e] < 0 ? (unsigned long long)(-COEF[j][e]) : (unsigned long long)COEF[j][e];
+}
+__host__ __device__ constexpr int coef_tz(int j, int e)
+{
+    unsigned long long m = coef_abs(j, e);
+    int k = 0;
+    while (m && !(m & 1)) { m >>= 1; k++; }
+    return k;
+}
+constexpr bool coef_odd_parts_fit()
+{
+    for (int j = 0; j < 5; j++)
+        for (int e = 0; e < 5; e++)
+            if ((coef_abs(j, e) >> coef_tz(j, e)) >> 32) return false;
+    return true;
+}
+static_assert(coef_odd_parts_fit(), "odd part of a CIC combination constant exceeds 32 bits");
+
+__device__ __forceinline__ unsigned long long coef_mul(int j, int e, unsigned long long b)
+{
+    const unsigned long long mag = coef_abs(j, e);
+    if (mag == 0) return 0;
+    const int tz = coef_tz(j, e);
+    const uint32_t odd = (uint32_t)(mag >> tz);
+    const unsigned long long lo = (unsigned long long)odd * (uint32_t)b;
+    const unsigned long long hi = (unsigned long long)(odd * (uint32_t)(b >> 32)) << 32;
+    const unsigned long long t = (lo + hi) << tz;
+    return COEF[j][e] < 0 ? 0ull - t : t;
+}
+
+// convergent rounding as the generated HDL codes it, on the low `bits` bits
+__device__ __forceinline__ int cround32(uint32_t v, int s, int bits)
+{
+    const int sh = 32 - bits;
+    const int t = (int)(v << sh) >> sh;
+    const uint32_t u = (uint32_t)t + ((1u << (s - 1)) - 1u) + (((uint32_t)t >> s) & 1u);
+    return ((int)(u << sh) >> sh) >> s;
+}
+
+__constant__ int16_t c_rx_ciccomp_h[65];
+__constant__ int16_t c_rx_hilb_c[256];
+// rx_ciccomp taps as the kernel multiplies them: pair m = {h[64-2m] | h[63-2m] << 16}, m = 0..31, and {h[0] | 0}
+__constant__ uint32_t c_ciccomp_pairs[33];
+
+constexpr int kTailTile = 1024; // outputs per workgroup of the two 48 kHz kernels (256 threads x 4)
+
+__constant__ uint32_t c_hilb_pairs[128]; // {c[255-2m] | c[254-2m] << 16}
+__constant__ uint32_t c_hilb_pairs_pad[144]; // the same at [3 + m], zeros around: the sliding window needs no bounds
+__constant__ uint32_t c_hilb_odd[8];     // bit j of the 256-bit mask: c[255-j] & 1
+__constant__ uint32_t c_hilb_bit1[8];    // bit j: (c[255-j] >> 1) & 1
+
+/*
+ * The two 48 kHz stages as functions over LDS arrays, shared by the stand-alone
+ * kernels further down and by ddc_rx_tail (rx_tile_finish).
+ *
+ * rx_ciccomp: e[n] = wrap16(cround(sum_{i=0..64} h[i] * c[2n-i], 15)) for I and Q
+ * (FPGA/rx_ciccomp.vhd:616; only the low 31 bits of the sum matter, so the sums
+ * run mod 2^32).  The rx_cic samples are split into an I and a Q array of int16,
+ * so that a dword holds two consecutive samples of one branch and one v_dot2 does
+ * two taps; a thread computes four consecutive outputs from a sliding window of
+ * 36 pairs (nine 16-byte LDS reads per branch, contiguous across the lanes):
+ * outputs 4 q + k, k = 0..3, use pairs (4 q + k) + m, m = 0..32; pi / pq point at
+ * quad q of the two arrays.  Returns {I | Q << 16} per output.
+ */
+__device__ __forceinline__ void ciccomp_quad(const uint4 *pi, const uint4 *pq, uint32_t (&packed)[4])
+{
+    int ai[4] = {0, 0, 0, 0}, aq[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const uint4 vi = pi[q], vq = pq[q];
+        const uint32_t wi[4] = { vi.x, vi.y, vi.z, vi.w }, wq[4] = { vq.x, vq.y, vq.z, vq.w };
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int m = 4 * q + e - k;
+                if (m >= 0 && m < 33) {
+                    ai[k] = dot2(wi[e], c_ciccomp_pairs[m], ai[k]);
+                    aq[k] = dot2(wq[e], c_ciccomp_pairs[m], aq[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int16_t ei = (int16_t)cround32((uint32_t)ai[k], 15, 31), eq = (int16_t)cround32((uint32_t)aq[k], 15, 31);
+        packed[k] = (uint32_t)(uint16_t)ei | ((uint32_t)(uint16_t)eq << 16);
+    }
+}
+
+/*
+ * rx_hilb: wrap16(cround(wrap30(sum_k cround(c[k]*x[n-k], 1)), 14)) (FPGA/rx_hilb.vhd:902-935).
+ *
+ * The per-product rounding is taken out of the tap loop.  With p = c*x,
+ * cround(p, 1) = floor(p / 2) + [p = 3 mod 4], so
+ *     sum_k cround(p_k, 1) = (S - N1) / 2 + N3,
+ * S = sum p_k (a plain dot product: v_dot2 on sample pairs), N1 = number of odd
+ * products, N3 = number of products = 3 mod 4.  N1 and N3 depend only on the two
+ * low bits of taps and samples: with the samples' bit 0 / bit 1 as bit planes and
+ * the taps' as constant masks they are population counts, 8 dwords per output.
+ * Only the low 30 bits of the sum matter, so everything runs mod 2^32.
+ *
+ * A tile is 1024 consecutive outputs of one channel computed from the 1279
+ * samples they reach (tile sample u = the sample 255 - u before the tile's first
+ * output), staged in LDS twice (xs[0]: pairs (2m, 2m+1); xs[1]: pairs (2m+1, 2m+2),
+ * so that odd outputs also read aligned pairs) plus the two bit planes.  A thread
+ * computes four outputs of one parity, two samples apart, from a sliding window of
+ * 131 pairs (33 16-byte LDS reads, contiguous across the lanes): thread (par, g)
+ * has outputs o_k = 8 g + par + 2 k, k = 0..3, output k uses pairs (4 g + k) + m,
+ * m = 0..127, of array par.
+ */
+constexpr int kHilbIn = kTailTile + 256;         // 1280 staged samples (1279 used)
+
+__device__ __forceinline__ void hilbert_quad_sums(const uint4 *src, int (&S)[4])
+{
+    S[0] = S[1] = S[2] = S[3] = 0;
+    // quad q holds pairs 4 q + e; output k multiplies pair j with tap pair j - k, i.e. taps
+    // 4 q - 3 .. 4 q + 3 (zero outside 0..127): seven scalar loads per quad
+#pragma unroll 3
+    for (int q = 0; q < 33; q++) {
+        const uint4 v = src[q];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        uint32_t c[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) c[i] = c_hilb_pairs_pad[4 * q + i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) S[k] = dot2(w[e], c[3 + e - k], S[k]);
+        }
+    }
+}
+
+// output o of the tile from its plain dot product S and the bit planes
+__device__ __forceinline__ int16_t hilbert_round(int S, uint32_t o, const uint32_t *p0, const uint32_t *p1)
+{
+    const uint32_t w0 = o >> 5, sh = o & 31u;
+    uint32_t n1 = 0, n3 = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const uint32_t a0 = __builtin_amdgcn_alignbit(p0[w0 + d + 1], p0[w0 + d], sh);
+        const uint32_t a1 = __builtin_amdgcn_alignbit(p1[w0 + d + 1], p1[w0 + d], sh);
+        const uint32_t both = a0 & c_hilb_odd[d];
+        n1 += __popc(both);
+        n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
+    }
+    const uint32_t acc = (((uint32_t)S - n1) >> 1) + n3;
+    return (int16_t)cround32(acc, 14, 30);
+}
+
+// Bit planes of the staged samples sa[0 .. kHilbIn): all 256 threads, after the samples are in LDS.
+__device__ __forceinline__ void hilbert_planes(const int16_t *sa, uint32_t *p0, uint32_t *p1, uint32_t t)
+{
+#pragma unroll
+    for (uint32_t u = t; u < (uint32_t)kHilbIn; u += 256) {
+        const int v = sa[u];
+        const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2);
+        if ((t & 63u) == 0) {
+            const uint32_t w = u >> 5;
+            p0[w] = (uint32_t)b0; p0[w + 1] = (uint32_t)(b0 >> 32);
+            p1[w] = (uint32_t)b1; p1[w + 1] = (uint32_t)(b1 >> 32);
+        }
+    }
+    if (t == 0) { p0[kHilbIn / 32] = 0; p0[kHilbIn / 32 + 1] = 0; p1[kHilbIn / 32] = 0; p1[kHilbIn / 32 + 1] = 0; }
+}
+
+/*
+ * The two-kernel RX call (ddc_rx_front_cic, ddc_rx_tail).  Between the kernels:
+ *
+ *   cic       [channel][kCicHist + n_blk][2] int16: rx_cic outputs of this call at
+ *             kCicHist + m (the kCicHist slots in front are unused here); a
+ *             workgroup of the first kernel writes the 251 outputs whose five windows
+ *             it owns itself
+ *   edge      [channel][n_wg][kEdgeRecs][10] u64: the moments of a workgroup's first
+ *             four and last five windows, from which the second kernel makes up the five
+ *             outputs at every workgroup boundary
+ *
+ * Tile j of a channel (frames 1024 j .. 1024 j + 1023 of the call) reads the rx_cic
+ * outputs 2048 j - 576 .. 2048 j + 2047: its own 2048, 64 the compensator reaches back,
+ * 512 more to recompute the 256 compensator outputs the Hilbert filter reaches back, so
+ * no tile waits for another.  Tile 0 takes what lies before the call from the saved
+ * histories.  Inside the second kernel, with several tiles per channel:
+ *
+ *   comp_tail [channel][kCompHist][2]: the last 256 compensator outputs of the call,
+ *             stored write-through (sc1) by the last tile's workgroup
+ *   chan_cnt  [channel]: arrival counter, zero between calls; every tile's workgroup
+ *             waits for its stores and adds one, the one whose add completes the count
+ *             runs an agent-scope acquire and saves the channel's new histories, mixer
+ *             carries and NCO phase.  No workgroup ever waits for another one.
+ */
+constexpr int kEdgeRecs = 9;
+constexpr int kWgPerTile = 2 * kTailTile / kFrontThreads;  // 8 workgroups of 256 windows per 1024 frames
+
+struct RxFused {
+    int16_t *cic;
+    unsigned long long *edge;
+    uint32_t *comp_tail;
+    uint32_t *chan_cnt;
+    unsigned long long *hist_mom;    // [channel][kMomHist][10]
+    int16_t *hist_cic, *hist_comp;   // [channel][kCicHist][2], [channel][kCompHist][2]
+    uint32_t *carry_saved, *carry_work, *acc0;
+    const uint32_t *phi32v;
+    int16_t *spec_iq, *voice_iq;
+    uint32_t n_wg, n_tiles, samples_lo;
+};
+
+// byte offsets into the 32 KB line buffer while a tile runs
+constexpr int kTailIn = 2 * (kTailTile + 256) + 64;        // rx_cic samples per branch a tile stages
+constexpr uint32_t kLdsSi = 0, kLdsSq = 5376;              // int16[kTailIn + 16] each
+constexpr uint32_t kLdsXs = 10752;                         // uint32[2][kHilbIn / 2]
+constexpr uint32_t kLdsP0 = 15872, kLdsP1 = 16128;         // uint32[kHilbIn / 32 + 2] each
+constexpr uint32_t kLdsCq = 16384;                         // int16[kHilbIn]: compensator Q of frames n0 - 256 ..
+constexpr uint32_t kLdsFlag = 20480;                       // uint32[4]
+static_assert((kTailIn + 16) * 2 <= (int)(kLdsSq - kLdsSi) && kLdsXs - kLdsSq == kLdsSq - kLdsSi, "tile LDS layout");
+static_assert(kLdsXs + 4 * kHilbIn <= kLdsP0 && kLdsCq + 2 * kHilbIn <= kLdsFlag && kLdsFlag >= 10 * 256 * 8, "tile LDS layout");
+
+// Write-through stores (global_store ... sc1): visible to every other workgroup of the launch
+// once the storing wave's s_waitcnt vmcnt(0) has passed, with no L2 write-back.
+__device__ __forceinline__ void store_wt(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_wt(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One relaxed add to an arrival counter by one lane, after every wave of the workgroup
+// has waited for its write-through stores and passed a barrier; `true` when this add
+// completed the count (the counter is then put back to zero for the next call).
+__device__ __forceinline__ bool count_in(uint32_t *cnt, uint32_t need)
+{
+    const uint32_t old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u != need) return false;
+    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+// The five rx_cic outputs at the front of workgroup kk (m = 256 kk + r, r = 0..4) reach
+// into the previous workgroup's windows: made from the edge records (or, for kk = 0, the
+// saved moments of the previous call).
+__device__ __forceinline__ uint32_t cic_edge_output(const unsigned long long *edge_ch, const unsigned long long *hist_ch,
+                                                    uint32_t kk, uint32_t r)
+{
+    unsigned long long acc[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int p = (int)r - 1 - j;   // window m - 1 - j relative to the workgroup's first
+        const unsigned long long *rec;
+        if (p >= 0) rec = edge_ch + ((size_t)kk * kEdgeRecs + p) * 10;
+        else if (kk > 0) rec = edge_ch + ((size_t)(kk - 1) * kEdgeRecs + 9 + p) * 10;
+        else rec = hist_ch + (5 + p) * 10;
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            acc[0] += coef_mul(j, e, rec[e]);
+            acc[1] += coef_mul(j, e, rec[5 + e]);
+        }
+    }
+    const uint32_t yi = (uint32_t)(uint16_t)(int16_t)((long long)(acc[0] << 3) >> 48);
+    const uint32_t yq = (uint32_t)(uint16_t)(int16_t)((long long)(acc[1] << 3) >> 48);
+    return yi | (yq << 16);
+}
+
+// rx_ciccomp, rx_hilb and data_delay for frames 1024 j .. of channel ch; all 256 threads.
+__device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, uint32_t j, uint32_t n_blk, char *lds,
+                                               uint32_t t)
+{
+    const uint32_t nf = n_blk / 2, n0 = j * (uint32_t)kTailTile;
+    const uint32_t n1 = n0 + kTailTile < nf ? n0 + kTailTile : nf;
+    const bool halo = j != 0;
+    int16_t *si = reinterpret_cast<int16_t *>(lds + kLdsSi), *sq = reinterpret_cast<int16_t *>(lds + kLdsSq);
+    uint32_t *xa = reinterpret_cast<uint32_t *>(lds + kLdsXs);
+    int16_t *sa = reinterpret_cast<int16_t *>(xa), *sb = sa + kHilbIn;
+    uint32_t *p0 = reinterpret_cast<uint32_t *>(lds + kLdsP0), *p1 = reinterpret_cast<uint32_t *>(lds + kLdsP1);
+    int16_t *cq = reinterpret_cast<int16_t *>(lds + kLdsCq);
+
+    // rx_cic samples c_lo .. 2 n1 - 1 of the call (negative: the saved history)
+    const int c_lo = 2 * (int)n0 - kCicHist - (halo ? 512 : 0);
+    const uint32_t count = (uint32_t)(2 * (int)n1 - c_lo);
+    uint32_t *cic32 = reinterpret_cast<uint32_t *>(fa.cic) + (size_t)ch * (kCicHist + n_blk) + kCicHist;
+    const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(fa.hist_cic) + (size_t)ch * kCicHist;
+    for (uint32_t s = t; s < (uint32_t)kTailIn + 16; s += 256) {
+        const int c = c_lo + (int)s;
+        uint32_t v = 0;
+        if (s < count) {
+            if (c < 0) v = hc32[kCicHist + c];
+            else if ((c & 255) >= 5) v = cic32[c];
+            else continue; // a workgroup-boundary output: made up just below
+        }
+        si[s] = (int16_t)(v & 0xFFFFu);
+        sq[s] = (int16_t)(v >> 16);
+    }
+    {
+        const uint32_t k_first = halo ? j * kWgPerTile - 2 : 0;
+        const uint32_t k_end = (j + 1) * kWgPerTile < fa.n_wg ? (j + 1) * kWgPerTile : fa.n_wg;
+        const uint32_t kk = k_first + t / 5, r = t % 5;
+        if (t < 5 * (kWgPerTile + 2) && kk < k_end) {
+            const uint32_t v = cic_edge_output(fa.edge + (size_t)ch * fa.n_wg * kEdgeRecs * 10,
+                                               fa.hist_mom + (size_t)ch * kMomHist * 10, kk, r);
+            const uint32_t m = kk * 256u + r;
+            cic32[m] = v; // for the debug tap; a neighbouring tile may write the same value
+            const uint32_t s = (uint32_t)((int)m - c_lo);
+            si[s] = (int16_t)(v & 0xFFFFu);
+            sq[s] = (int16_t)(v >> 16);
+        }
+    }
+    // tile 0: the 256 compensator outputs before the call come from the saved history
+    if (!halo) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(fa.hist_comp)[(size_t)ch * kCompHist + t];
+        if (t >= 1) sa[t - 1] = (int16_t)(v & 0xFFFFu);
+        if (t >= 2) sb[t - 2] = (int16_t)(v & 0xFFFFu);
+        cq[t] = (int16_t)(v >> 16);
+    }
+    __syncthreads();
+
+    // compensator outputs of frames f_lo .. n1 - 1
+    const uint32_t f_lo = n0 - (halo ? 256u : 0u), n_out = n1 - f_lo;
+    uint32_t *spec32 = reinterpret_cast<uint32_t *>(fa.spec_iq) + (size_t)ch * nf;
+#pragma unroll 1
+    for (uint32_t o = 4 * t; o < n_out; o += 1024) {
+        uint32_t packed[4];
+        ciccomp_quad(reinterpret_cast<const uint4 *>(si) + o / 4, reinterpret_cast<const uint4 *>(sq) + o / 4, packed);
+        const uint32_t f = f_lo + o;
+        const int u0 = (int)(f + 255u) - (int)n0; // Hilbert tile sample of frame f
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = u0 + k;
+            if (u >= 0) sa[u] = (int16_t)(packed[k] & 0xFFFFu);
+            if (u >= 1) sb[u - 1] = (int16_t)(packed[k] & 0xFFFFu);
+            cq[u + 1] = (int16_t)(packed[k] >> 16);
+        }
+        if (f + kCompHist >= nf) { // among the last 256 outputs of the call: what rx_hilb reaches back to next time
+#pragma unroll
+            for (int k = 0; k < 4; k++) store_wt(fa.comp_tail + (size_t)ch * kCompHist + (f + k + kCompHist - nf), packed[k]);
+        }
+        if (f >= n0) { // frame counts are multiples of 128: a quad is never cut
+            if (((uintptr_t)(spec32 + f) & 15u) == 0) *reinterpret_cast<uint4 *>(spec32 + f) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            else { spec32[f] = packed[0]; spec32[f + 1] = packed[1]; spec32[f + 2] = packed[2]; spec32[f + 3] = packed[3]; }
+        }
+    }
+    __syncthreads();
+    {
+        // samples beyond the last frame of a short tile read as zero
+        const uint32_t n_valid = 255u + (n1 - n0);
+        for (uint32_t u = n_valid + t; u < (uint32_t)kHilbIn; u += 256) { sa[u] = 0; sb[u - 1] = 0; }
+        if (t == 0) sb[kHilbIn - 1] = 0;
+    }
+    __syncthreads();
+    hilbert_planes(sa, p0, p1, t);
+    __syncthreads();
+
+    const uint32_t par = t >> 7, g = t & 127u;
+    int S[4];
+    hilbert_quad_sums(reinterpret_cast<const uint4 *>(xa) + par * (kHilbIn / 8) + g, S);
+    uint32_t *voice32 = reinterpret_cast<uint32_t *>(fa.voice_iq) + (size_t)ch * nf;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
+        if (n >= n1) continue;
+        const int16_t vi = hilbert_round(S[k], o, p0, p1);
+        const int16_t vq = cq[o + 126]; // frame n - 130 (FPGA/data_delay.v, delay_length = 130)
+        voice32[n] = (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
+    }
+}
+
+// What one channel carries into the next call; all 256 threads, after every tile of the channel.
+__device__ __forceinline__ void rx_channel_finish(const RxFused &fa, uint32_t ch, uint32_t n_blk, uint32_t t)
+{
+    const uint32_t nf = n_blk / 2;
+    if (t < kMomHist * 10)
+        fa.hist_mom[(size_t)ch * kMomHist * 10 + t] =
+            fa.edge[(((size_t)ch * fa.n_wg + fa.n_wg - 1) * kEdgeRecs + 4) * 10 + t];
+    const uint32_t *cic32 = reinterpret_cast<const uint32_t *>(fa.cic) + (size_t)ch * (kCicHist + n_blk) + kCicHist;
+    if (t < kCicHist)
+        reinterpret_cast<uint32_t *>(fa.hist_cic)[(size_t)ch * kCicHist + t] = cic32[n_blk - kCicHist + t];
+    uint32_t *he = reinterpret_cast<uint32_t *>(fa.hist_comp) + (size_t)ch * kCompHist;
+    uint32_t v;
+    if (nf >= (uint32_t)kCompHist || t >= kCompHist - nf) v = fa.comp_tail[(size_t)ch * kCompHist + t];
+    else v = he[t + nf];
+    __syncthreads(); // a short call shifts the old history in place
+    he[t] = v;
+    if (t < 6) fa.carry_saved[ch * 6 + t] = fa.carry_work[ch * 6 + t];
+    if (t == 0) fa.acc0[ch] += fa.samples_lo * fa.phi32v[ch];
+}
+
+// After the sample loop of ddc_rx_front_cic: thread t holds the moments of window b = 256 k + t of
+// channel ch.  rx_cic output m needs windows m-5 .. m-1 (FPGA/rx_cic.vhd:291-404 as the 5 x 5
+// combination of tools/cic_math.py): every thread applies the five rows of COEF to its own
+// moments, P[j] = sum_e COEF[j][e] B[e] = what its window adds to output b + 1 + j, the P's go
+// through LDS, and thread t sums the five that make output b (threads 0..4 lack windows of the
+// workgroup before: their outputs are made up from the edge records by ddc_rx_tail).
+__device__ __forceinline__ void rx_cic_epilogue(const RxFused &fa, uint32_t ch, uint32_t b, uint32_t n_blk,
+                                                const unsigned long long (&Bi)[5], const unsigned long long (&Bq)[5],
+                                                char *lds, uint32_t t)
+{
+    const uint32_t k = b >> 8;
+    unsigned long long *px = reinterpret_cast<unsigned long long *>(lds); // [10][256]
+    __syncthreads(); // the hand-over of the mixer outputs has been read
+    px[t] = Bi[4];        // COEF[0] = (0, 0, 0, 0, 1)
+    px[5 * 256 + t] = Bq[4];
+#pragma unroll
+    for (int j = 1; j < 5; j++) {
+        unsigned long long pi = 0, pq = 0;
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            pi += coef_mul(j, e, Bi[e]);
+            pq += coef_mul(j, e, Bq[e]);
+        }
+        px[j * 256 + t] = pi;
+        px[(5 + j) * 256 + t] = pq;
+    }
+    if (t < 4 || t >= 251) {
+        unsigned long long *rec = fa.edge + (((size_t)ch * fa.n_wg + k) * kEdgeRecs + (t < 4 ? t : t - 247)) * 10;
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            rec[e] = Bi[e];
+            rec[5 + e] = Bq[e];
+        }
+    }
+    __syncthreads();
+    if (t >= 5) {
+        unsigned long long yi = 0, yq = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            yi += px[j * 256 + t - 1 - j];
+            yq += px[(5 + j) * 256 + t - 1 - j];
+        }
+        // bits 59..44 of the sum (FPGA/rx_cic.vhd:391); the moments are of 2 x, so one place up
+        const uint32_t oi = (uint32_t)(uint16_t)(int16_t)((long long)(yi << 3) >> 48);
+        const uint32_t oq = (uint32_t)(uint16_t)(int16_t)((long long)(yq << 3) >> 48);
+        reinterpret_cast<uint32_t *>(fa.cic)[(size_t)ch * (kCicHist + n_blk) + kCicHist + b] = oi | (oq << 16);
+    }
+}
+
 /*
  * Kernel 1.  One thread owns one natural block of 512 samples of one channel
  * (global block id g = channel * n_blk + block); a workgroup owns 256
@@ -361,11 +800,12 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
  */
 __device__ __forceinline__ uint32_t line_swz(uint32_t row) { return ((row >> 1) & 3u) ^ (((row >> 3) & 1u) << 2); }
 
-__global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
+template <bool FUSED>
+__device__ __forceinline__ void rx_front_body(
     const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t total_blocks,
-    const uint32_t *__restrict__ acc0, const uint32_t *__restrict__ phi32v,
-    const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out,
-    unsigned long long *__restrict__ mom, const uint2 *__restrict__ nco_tab)
+    const uint32_t *acc0, const uint32_t *__restrict__ phi32v,
+    const uint32_t *carry_in, uint32_t *carry_out,
+    unsigned long long *__restrict__ mom, const uint2 *__restrict__ nco_tab, const RxFused &fa)
 {
     __shared__ uint2 tab[2048];
     __shared__ uint4 lines[8 * kFrontThreads];
@@ -521,16 +961,10 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
         cq.inject_first(mq);
     }
 
-    if (!active) return;
+    if (!FUSED && !active) return;
     unsigned long long Bi[5], Bq[5];
     ci.moments(Bi);
     cq.moments(Bq);
-    unsigned long long *rec = mom + ((size_t)ch * (kMomHist + n_blk) + kMomHist + b) * 10;
-#pragma unroll
-    for (int e = 0; e < 5; e++) {
-        rec[e] = Bi[e];
-        rec[5 + e] = Bq[e];
-    }
     if (b == n_blk - 1) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -538,41 +972,66 @@ __global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
             carry_out[ch * 6 + 3 + k] = last_q[k];
         }
     }
+    if (!FUSED) {
+        unsigned long long *rec = mom + ((size_t)ch * (kMomHist + n_blk) + kMomHist + b) * 10;
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            rec[e] = Bi[e];
+            rec[5 + e] = Bq[e];
+        }
+        return;
+    }
+    rx_cic_epilogue(fa, ch, b, n_blk, Bi, Bq, reinterpret_cast<char *>(lines), tid);
 }
 
-// COEF[j][e] * b mod 2^64 with the constant split into sign, an odd factor below
-// 2^32 and a power of two: a 32 x 64 bit product and a shift instead of a full
-// 64 x 64 bit multiply (the small odd factors fold into shifts and adds).
-__host__ __device__ constexpr unsigned long long coef_abs(int j, int e)
+/* The ingest kernel of the call plan with separate kernels (any block count). */
+__global__ __launch_bounds__(kFrontThreads) void ddc_rx_front(
+    const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t total_blocks,
+    const uint32_t *__restrict__ acc0, const uint32_t *__restrict__ phi32v,
+    const uint32_t *__restrict__ carry_in, uint32_t *__restrict__ carry_out,
+    unsigned long long *__restrict__ mom, const uint2 *__restrict__ nco_tab)
 {
-    return COEF[j][e] < 0 ? (unsigned long long)(-COEF[j][e]) : (unsigned long long)COEF[j][e];
+    rx_front_body<false>(adc, row_bytes, n_blk, total_blocks, acc0, phi32v, carry_in, carry_out, mom, nco_tab, RxFused{});
 }
-__host__ __device__ constexpr int coef_tz(int j, int e)
-{
-    unsigned long long m = coef_abs(j, e);
-    int k = 0;
-    while (m && !(m & 1)) { m >>= 1; k++; }
-    return k;
-}
-constexpr bool coef_odd_parts_fit()
-{
-    for (int j = 0; j < 5; j++)
-        for (int e = 0; e < 5; e++)
-            if ((coef_abs(j, e) >> coef_tz(j, e)) >> 32) return false;
-    return true;
-}
-static_assert(coef_odd_parts_fit(), "odd part of a CIC combination constant exceeds 32 bits");
 
-__device__ __forceinline__ unsigned long long coef_mul(int j, int e, unsigned long long b)
+/*
+ * Kernel 1 of the two-kernel call plan, for block counts that are a multiple of 256 (a
+ * workgroup then owns 256 consecutive windows of ONE channel): ingest as above, then
+ * the workgroup turns its windows' moments into rx_cic outputs through LDS
+ * (rx_cic_epilogue) and leaves only nine edge records per workgroup in memory.
+ */
+__global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_cic(
+    const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t total_blocks,
+    const uint32_t *__restrict__ phi32v, const uint2 *__restrict__ nco_tab, const RxFused fa)
 {
-    const unsigned long long mag = coef_abs(j, e);
-    if (mag == 0) return 0;
-    const int tz = coef_tz(j, e);
-    const uint32_t odd = (uint32_t)(mag >> tz);
-    const unsigned long long lo = (unsigned long long)odd * (uint32_t)b;
-    const unsigned long long hi = (unsigned long long)(odd * (uint32_t)(b >> 32)) << 32;
-    const unsigned long long t = (lo + hi) << tz;
-    return COEF[j][e] < 0 ? 0ull - t : t;
+    rx_front_body<true>(adc, row_bytes, n_blk, total_blocks, fa.acc0, phi32v, fa.carry_saved, fa.carry_work, nullptr, nco_tab, fa);
+}
+
+/*
+ * Kernel 2 of the two-kernel call plan: one workgroup per (channel, tile of 1024 frames)
+ * runs rx_ciccomp, rx_hilb and data_delay for the tile (rx_tile_finish); the workgroup
+ * that finishes a channel's last tile then saves what the channel carries into the
+ * next call (rx_channel_finish).  With several tiles per channel that workgroup is
+ * found by an arrival counter: tile 0 reads the old histories which the save overwrites.
+ */
+__global__ __launch_bounds__(256) void ddc_rx_tail(uint32_t n_blk, const RxFused fa)
+{
+    __shared__ __align__(16) char lds[kLdsFlag + 16];
+    const uint32_t t = threadIdx.x, ch = blockIdx.x / fa.n_tiles, j = blockIdx.x - ch * fa.n_tiles;
+    rx_tile_finish(fa, ch, j, n_blk, lds, t);
+    uint32_t *flag = reinterpret_cast<uint32_t *>(lds + kLdsFlag);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores of comp_tail have landed
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t last = fa.n_tiles > 1 ? (count_in(fa.chan_cnt + ch, fa.n_tiles) ? 1u : 0u) : 1u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0]) rx_channel_finish(fa, ch, n_blk, t);
 }
 
 /*
@@ -643,33 +1102,11 @@ __global__ __launch_bounds__(256) void ddc_adc_minmax(const uint8_t *__restrict_
     if (threadIdx.x == 0) { atomicMin(&mn[ch], s_mn); atomicMax(&mx[ch], s_mx); }
 }
 
-// convergent rounding as the generated HDL codes it, on the low `bits` bits
-__device__ __forceinline__ int cround32(uint32_t v, int s, int bits)
-{
-    const int sh = 32 - bits;
-    const int t = (int)(v << sh) >> sh;
-    const uint32_t u = (uint32_t)t + ((1u << (s - 1)) - 1u) + (((uint32_t)t >> s) & 1u);
-    return ((int)(u << sh) >> sh) >> s;
-}
-
-__constant__ int16_t c_rx_ciccomp_h[65];
-__constant__ int16_t c_rx_hilb_c[256];
-// rx_ciccomp taps as the kernel multiplies them: pair m = {h[64-2m] | h[63-2m] << 16}, m = 0..31, and {h[0] | 0}
-__constant__ uint32_t c_ciccomp_pairs[33];
-
-constexpr int kTailTile = 1024; // outputs per workgroup of the two 48 kHz kernels (256 threads x 4)
 
 /*
- * Kernel 3.  rx_ciccomp: e[n] = wrap16(cround(sum_{i=0..64} h[i] * c[2n-i], 15))
- * for I and Q (FPGA/rx_ciccomp.vhd:616; only the low 31 bits of the sum matter,
- * so the sums run mod 2^32).  Writes SPEC I/Q to the caller and to
- * comp: [channel][kCompHist + nf][2].
- *
- * A workgroup computes 1024 consecutive outputs of one channel.  The 2112 rx_cic
- * samples they reach are split into an I and a Q array of int16 in LDS, so that a
- * dword holds two consecutive samples of one branch and one v_dot2 does two taps;
- * a thread computes four consecutive outputs from a sliding window of 36 pairs
- * (nine 16-byte LDS reads per branch, contiguous across the lanes).
+ * Kernel 3 of the call plan with separate kernels.  rx_ciccomp (ciccomp_quad) for
+ * 1024 consecutive outputs of one channel per workgroup; writes SPEC I/Q to the
+ * caller and to comp: [channel][kCompHist + nf][2].
  */
 __global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, uint32_t tiles,
                                                      int16_t *__restrict__ comp, int16_t *__restrict__ spec_iq)
@@ -689,33 +1126,10 @@ __global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict_
         sq[j] = (int16_t)(v >> 16);
     }
     __syncthreads();
-    // outputs n0 + 4 t + k, k = 0..3: output k uses pairs (4 t + k) + m, m = 0..32, of the staged arrays
-    const uint4 *pi = reinterpret_cast<const uint4 *>(si) + t, *pq = reinterpret_cast<const uint4 *>(sq) + t;
-    int ai[4] = {0, 0, 0, 0}, aq[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const uint4 vi = pi[q], vq = pq[q];
-        const uint32_t wi[4] = { vi.x, vi.y, vi.z, vi.w }, wq[4] = { vq.x, vq.y, vq.z, vq.w };
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int m = 4 * q + e - k;
-                if (m >= 0 && m < 33) {
-                    ai[k] = dot2(wi[e], c_ciccomp_pairs[m], ai[k]);
-                    aq[k] = dot2(wq[e], c_ciccomp_pairs[m], aq[k]);
-                }
-            }
-        }
-    }
+    uint32_t packed[4];
+    ciccomp_quad(reinterpret_cast<const uint4 *>(si) + t, reinterpret_cast<const uint4 *>(sq) + t, packed);
     const uint32_t n = n0 + 4 * t;
     if (n >= nf) return;
-    uint32_t packed[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int16_t ei = (int16_t)cround32((uint32_t)ai[k], 15, 31), eq = (int16_t)cround32((uint32_t)aq[k], 15, 31);
-        packed[k] = (uint32_t)(uint16_t)ei | ((uint32_t)(uint16_t)eq << 16);
-    }
     uint32_t *oc = reinterpret_cast<uint32_t *>(comp) + (size_t)ch * (kCompHist + nf) + kCompHist + n;
     uint32_t *os = reinterpret_cast<uint32_t *>(spec_iq) + (size_t)ch * nf + n;
     if (n + 3 < nf && (nf & 3u) == 0 && ((uintptr_t)os & 15u) == 0) { // whole quad, 16-byte aligned rows
@@ -729,93 +1143,41 @@ __global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict_
 }
 
 /*
- * Kernel 4.  VOICE_I = rx_hilb(e_I): wrap16(cround(wrap30(sum_k cround(c[k]*x[n-k], 1)), 14))
- * (FPGA/rx_hilb.vhd:902-935); VOICE_Q = e_Q delayed by 130 (FPGA/data_delay.v).
- *
- * The per-product rounding is taken out of the tap loop.  With p = c*x,
- * cround(p, 1) = floor(p / 2) + [p = 3 mod 4], so
- *     sum_k cround(p_k, 1) = (S - N1) / 2 + N3,
- * S = sum p_k (a plain dot product: v_dot2 on sample pairs), N1 = number of odd
- * products, N3 = number of products = 3 mod 4.  N1 and N3 depend only on the two
- * low bits of taps and samples: with the samples' bit 0 / bit 1 as bit planes and
- * the taps' as constant masks they are population counts, 8 dwords per output.
- * Only the low 30 bits of the sum matter, so everything runs mod 2^32.
- *
- * A workgroup computes 1024 consecutive outputs of one channel from the 1279
- * samples they reach, staged in LDS twice (the second copy one sample on, so
- * that odd outputs also read aligned pairs) plus the two bit planes.  A thread
- * computes four outputs of one parity, two samples apart, from a sliding window
- * of 131 pairs (33 16-byte LDS reads, contiguous across the lanes): waves 0-1
- * take the even outputs, waves 2-3 the odd ones.
+ * Kernel 4 of the call plan with separate kernels.  VOICE_I = rx_hilb(e_I)
+ * (hilbert_quad_sums / hilbert_round); VOICE_Q = e_Q delayed by 130
+ * (FPGA/data_delay.v).  A workgroup computes 1024 consecutive outputs of one
+ * channel: waves 0-1 take the even outputs, waves 2-3 the odd ones.
  */
-__constant__ uint32_t c_hilb_pairs[128]; // {c[255-2m] | c[254-2m] << 16}
-__constant__ uint32_t c_hilb_pairs_pad[144]; // the same at [3 + m], zeros around: the sliding window needs no bounds
-__constant__ uint32_t c_hilb_odd[8];     // bit j of the 256-bit mask: c[255-j] & 1
-__constant__ uint32_t c_hilb_bit1[8];    // bit j: (c[255-j] >> 1) & 1
-
 __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict__ comp, uint32_t nf, uint32_t tiles,
                                                      int16_t *__restrict__ voice_iq)
 {
-    constexpr int kIn = kTailTile + 256;             // 1280 staged samples (1279 used)
-    __shared__ __align__(16) uint32_t xs[2][kIn / 2]; // [0]: pairs (2m, 2m+1), [1]: pairs (2m+1, 2m+2)
-    __shared__ uint32_t p0[kIn / 32 + 2], p1[kIn / 32 + 2];
-    uint32_t *xa = xs[0], *xb = xs[1];
+    __shared__ __align__(16) uint32_t xs[2][kHilbIn / 2]; // [0]: pairs (2m, 2m+1), [1]: pairs (2m+1, 2m+2)
+    __shared__ uint32_t p0[kHilbIn / 32 + 2], p1[kHilbIn / 32 + 2];
     const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * (uint32_t)kTailTile, t = threadIdx.x;
     const uint32_t *x = reinterpret_cast<const uint32_t *>(comp) + (size_t)ch * (kCompHist + nf);
     const uint32_t last = kCompHist + nf - 1;
-    int16_t *sa = reinterpret_cast<int16_t *>(xa), *sb = reinterpret_cast<int16_t *>(xb);
+    int16_t *sa = reinterpret_cast<int16_t *>(xs[0]), *sb = reinterpret_cast<int16_t *>(xs[1]);
     // tile sample j is entry n0 + 1 + j of the channel (sample n0 - 255 + j)
 #pragma unroll
-    for (uint32_t j = t; j < (uint32_t)kIn; j += 256) {
+    for (uint32_t j = t; j < (uint32_t)kHilbIn; j += 256) {
         uint32_t e = n0 + 1 + j;
         e = e < last ? e : last;
-        const int v = (int)(int16_t)(x[e] & 0xFFFFu);
-        sa[j] = (int16_t)v;
-        if (j) sb[j - 1] = (int16_t)v;
-        const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2);
-        if ((t & 63u) == 0) {
-            const uint32_t w = j >> 5;
-            p0[w] = (uint32_t)b0; p0[w + 1] = (uint32_t)(b0 >> 32);
-            p1[w] = (uint32_t)b1; p1[w + 1] = (uint32_t)(b1 >> 32);
-        }
+        const int16_t v = (int16_t)(x[e] & 0xFFFFu);
+        sa[j] = v;
+        if (j) sb[j - 1] = v;
     }
-    if (t == 0) { p0[kIn / 32] = 0; p0[kIn / 32 + 1] = 0; p1[kIn / 32] = 0; p1[kIn / 32 + 1] = 0; sb[kIn - 1] = 0; }
+    if (t == 0) sb[kHilbIn - 1] = 0;
     __syncthreads();
-    // thread (par, g): outputs o_k = 8 g + par + 2 k, k = 0..3; output k uses pairs (4 g + k) + m, m = 0..127
+    hilbert_planes(sa, p0, p1, t);
+    __syncthreads();
     const uint32_t par = t >> 7, g = t & 127u;
-    const uint4 *src = reinterpret_cast<const uint4 *>(&xs[0][0]) + par * (kIn / 8) + g;
-    int S[4] = {0, 0, 0, 0};
-    // quad q holds pairs 4 q + e; output k multiplies pair j with tap pair j - k, i.e. taps
-    // 4 q - 3 .. 4 q + 3 (zero outside 0..127): seven scalar loads per quad
-#pragma unroll 3
-    for (int q = 0; q < 33; q++) {
-        const uint4 v = src[q];
-        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-        uint32_t c[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) c[i] = c_hilb_pairs_pad[4 * q + i];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) S[k] = dot2(w[e], c[3 + e - k], S[k]);
-        }
-    }
+    int S[4];
+    hilbert_quad_sums(reinterpret_cast<const uint4 *>(&xs[0][0]) + par * (kHilbIn / 8) + g, S);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
         if (n >= nf) continue;
-        const uint32_t w0 = o >> 5, sh = o & 31u;
-        uint32_t n1 = 0, n3 = 0;
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const uint32_t a0 = __builtin_amdgcn_alignbit(p0[w0 + d + 1], p0[w0 + d], sh);
-            const uint32_t a1 = __builtin_amdgcn_alignbit(p1[w0 + d + 1], p1[w0 + d], sh);
-            const uint32_t both = a0 & c_hilb_odd[d];
-            n1 += __popc(both);
-            n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
-        }
-        const uint32_t acc = (((uint32_t)S[k] - n1) >> 1) + n3;
-        const int16_t vi = (int16_t)cround32(acc, 14, 30);
+        const int16_t vi = hilbert_round(S[k], o, p0, p1);
         const int16_t vq = (int16_t)((int)x[kCompHist + n - 130] >> 16);
         reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
             (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);

@@ -81,6 +81,7 @@ def lib():
     L.ddc_rx_static_scratch_need.restype = sz
     L.ddc_rx_process.argtypes = [vp, vp, sz, sz, vp, vp]
     L.ddc_rx_read_cic.argtypes = [vp, vp, sz]
+    L.ddc_debug_rx_plan.argtypes = [vp, C.c_int]
     L.ddc_tx_process_dev.argtypes = [vp, vp, sz, vp]
     L.ddc_tx_process.argtypes = [vp, vp, sz, vp]
     L.ddc_tx_reset.argtypes = [vp, i32]
@@ -288,6 +289,10 @@ class Ddc:
         out = np.zeros((self.n_channels, samples // 512, 2), np.int16)
         self._check(self._L.ddc_rx_read_cic(self._h, _np_ptr(out), samples))
         return out
+
+    def debug_rx_plan(self, plan):
+        """0: call plan by size (one kernel when samples / 512 is a multiple of 256); 1: always the separate kernels."""
+        self._check(self._L.ddc_debug_rx_plan(self._h, int(plan)))
 
     def tx_process(self, iq48k):
         """Host path. iq48k: int16 [n_channels][n][2]; returns uint16 [n_channels][1024 n]."""
