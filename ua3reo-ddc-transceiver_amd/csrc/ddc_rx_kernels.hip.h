@@ -457,18 +457,25 @@ __device__ __forceinline__ void ciccomp_quad(const uint4 *pi, const uint4 *pq, u
  */
 constexpr int kHilbIn = kTailTile + 256;         // 1280 staged samples (1279 used)
 
-__device__ __forceinline__ void hilbert_quad_sums(const uint4 *src, int (&S)[4])
+// taps: c_hilb_pairs_pad copied to LDS (hilbert_stage_taps), so that the tap loop waits for no scalar load
+__device__ __forceinline__ void hilbert_stage_taps(uint32_t *taps, uint32_t t)
+{
+    if (t < 144) taps[t] = c_hilb_pairs_pad[t];
+}
+
+__device__ __forceinline__ void hilbert_quad_sums(const uint4 *src, const uint32_t *taps, int (&S)[4])
 {
     S[0] = S[1] = S[2] = S[3] = 0;
     // quad q holds pairs 4 q + e; output k multiplies pair j with tap pair j - k, i.e. taps
-    // 4 q - 3 .. 4 q + 3 (zero outside 0..127): seven scalar loads per quad
+    // 4 q - 3 .. 4 q + 3 (zero outside 0..127) = padded entries 4 q .. 4 q + 6: two 16-byte
+    // reads at an address all lanes share
+    const uint4 *tp = reinterpret_cast<const uint4 *>(taps);
 #pragma unroll 3
     for (int q = 0; q < 33; q++) {
         const uint4 v = src[q];
         const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-        uint32_t c[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) c[i] = c_hilb_pairs_pad[4 * q + i];
+        const uint4 c0 = tp[q], c1 = tp[q + 1];
+        const uint32_t c[7] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z };
 #pragma unroll
         for (int e = 0; e < 4; e++) {
 #pragma unroll
@@ -556,9 +563,10 @@ constexpr uint32_t kLdsSi = 0, kLdsSq = 5376;              // int16[kTailIn + 16
 constexpr uint32_t kLdsXs = 10752;                         // uint32[2][kHilbIn / 2]
 constexpr uint32_t kLdsP0 = 15872, kLdsP1 = 16128;         // uint32[kHilbIn / 32 + 2] each
 constexpr uint32_t kLdsCq = 16384;                         // int16[kHilbIn]: compensator Q of frames n0 - 256 ..
+constexpr uint32_t kLdsTaps = 19456;                       // uint32[144]: the padded Hilbert tap pairs
 constexpr uint32_t kLdsFlag = 20480;                       // uint32[4]
 static_assert((kTailIn + 16) * 2 <= (int)(kLdsSq - kLdsSi) && kLdsXs - kLdsSq == kLdsSq - kLdsSi, "tile LDS layout");
-static_assert(kLdsXs + 4 * kHilbIn <= kLdsP0 && kLdsCq + 2 * kHilbIn <= kLdsFlag && kLdsFlag >= 10 * 256 * 8, "tile LDS layout");
+static_assert(kLdsXs + 4 * kHilbIn <= kLdsP0 && kLdsCq + 2 * kHilbIn <= kLdsTaps && kLdsTaps + 4 * 144 <= kLdsFlag && kLdsFlag >= 10 * 256 * 8, "tile LDS layout");
 
 // Write-through stores (global_store ... sc1): visible to every other workgroup of the launch
 // once the storing wave's s_waitcnt vmcnt(0) has passed, with no L2 write-back.
@@ -625,17 +633,41 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
     const uint32_t count = (uint32_t)(2 * (int)n1 - c_lo);
     uint32_t *cic32 = reinterpret_cast<uint32_t *>(fa.cic) + (size_t)ch * (kCicHist + n_blk) + kCicHist;
     const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(fa.hist_cic) + (size_t)ch * kCicHist;
-    for (uint32_t s = t; s < (uint32_t)kTailIn + 16; s += 256) {
-        const int c = c_lo + (int)s;
-        uint32_t v = 0;
-        if (s < count) {
-            if (c < 0) v = hc32[kCicHist + c];
-            else if ((c & 255) >= 5) v = cic32[c];
-            else continue; // a workgroup-boundary output: made up just below
+    // four samples per 16-byte load, all loads of a thread in flight together
+    {
+        constexpr int kQuads = (kTailIn + 16) / 4;
+        uint4 v[(kQuads + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (kQuads + 255) / 256; i++) {
+            const uint32_t s = 4u * (t + 256u * i);
+            const int c = c_lo + (int)s;
+            const uint32_t *src = c < 0 ? hc32 + (kCicHist + c) : cic32 + c;
+            if (s >= count) src = cic32; // past the tile: any readable address, the value is dropped
+            v[i] = *reinterpret_cast<const uint4 *>(src);
         }
-        si[s] = (int16_t)(v & 0xFFFFu);
-        sq[s] = (int16_t)(v >> 16);
+#pragma unroll
+        for (int i = 0; i < (kQuads + 255) / 256; i++) {
+            const uint32_t s = 4u * (t + 256u * i);
+            const int c = c_lo + (int)s;
+            if (s >= (uint32_t)kTailIn + 16) continue;
+            if (s >= count) v[i] = make_uint4(0, 0, 0, 0);
+            // outputs 0..4 of every workgroup of the first kernel are made up just below
+            const uint32_t r = c >= 0 ? (uint32_t)c & 255u : 8u;
+            if (r == 0) continue;
+            const uint32_t i01 = __builtin_amdgcn_perm(v[i].y, v[i].x, 0x05040100u), i23 = __builtin_amdgcn_perm(v[i].w, v[i].z, 0x05040100u);
+            const uint32_t q01 = __builtin_amdgcn_perm(v[i].y, v[i].x, 0x07060302u), q23 = __builtin_amdgcn_perm(v[i].w, v[i].z, 0x07060302u);
+            if (r == 4) {
+                si[s + 1] = (int16_t)(i01 >> 16);
+                sq[s + 1] = (int16_t)(q01 >> 16);
+                *reinterpret_cast<uint32_t *>(si + s + 2) = i23;
+                *reinterpret_cast<uint32_t *>(sq + s + 2) = q23;
+            } else {
+                *reinterpret_cast<uint2 *>(si + s) = make_uint2(i01, i23);
+                *reinterpret_cast<uint2 *>(sq + s) = make_uint2(q01, q23);
+            }
+        }
     }
+    hilbert_stage_taps(reinterpret_cast<uint32_t *>(lds + kLdsTaps), t);
     {
         const uint32_t k_first = halo ? j * kWgPerTile - 2 : 0;
         const uint32_t k_end = (j + 1) * kWgPerTile < fa.n_wg ? (j + 1) * kWgPerTile : fa.n_wg;
@@ -675,7 +707,7 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
             if (u >= 1) sb[u - 1] = (int16_t)(packed[k] & 0xFFFFu);
             cq[u + 1] = (int16_t)(packed[k] >> 16);
         }
-        if (f + kCompHist >= nf) { // among the last 256 outputs of the call: what rx_hilb reaches back to next time
+        if (fa.n_tiles > 1 && f + kCompHist >= nf) { // the last 256 outputs of the call: what rx_hilb reaches back to next time
 #pragma unroll
             for (int k = 0; k < 4; k++) store_wt(fa.comp_tail + (size_t)ch * kCompHist + (f + k + kCompHist - nf), packed[k]);
         }
@@ -697,7 +729,8 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
 
     const uint32_t par = t >> 7, g = t & 127u;
     int S[4];
-    hilbert_quad_sums(reinterpret_cast<const uint4 *>(xa) + par * (kHilbIn / 8) + g, S);
+    hilbert_quad_sums(reinterpret_cast<const uint4 *>(xa) + par * (kHilbIn / 8) + g,
+                      reinterpret_cast<const uint32_t *>(lds + kLdsTaps), S);
     uint32_t *voice32 = reinterpret_cast<uint32_t *>(fa.voice_iq) + (size_t)ch * nf;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -709,24 +742,31 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
     }
 }
 
-// What one channel carries into the next call; all 256 threads, after every tile of the channel.
-__device__ __forceinline__ void rx_channel_finish(const RxFused &fa, uint32_t ch, uint32_t n_blk, uint32_t t)
+// What one channel carries into the next call, beside the compensator outputs: read from what the
+// first kernel left (any time in the second kernel), stored after every tile of the channel is done.
+struct ChannelCarry {
+    unsigned long long mom; // t < 50: the moments of the call's last five windows
+    uint32_t cic;           // t < 64: its last 64 rx_cic outputs
+    uint32_t carry;         // t < 6: mixer outputs of its last six samples
+    uint32_t phase;         // t = 0: NCO phase after the call
+};
+__device__ __forceinline__ void rx_channel_load(const RxFused &fa, uint32_t ch, uint32_t n_blk, uint32_t t, ChannelCarry &c)
 {
-    const uint32_t nf = n_blk / 2;
-    if (t < kMomHist * 10)
-        fa.hist_mom[(size_t)ch * kMomHist * 10 + t] =
-            fa.edge[(((size_t)ch * fa.n_wg + fa.n_wg - 1) * kEdgeRecs + 4) * 10 + t];
-    const uint32_t *cic32 = reinterpret_cast<const uint32_t *>(fa.cic) + (size_t)ch * (kCicHist + n_blk) + kCicHist;
+    c.mom = 0; c.cic = 0; c.carry = 0; c.phase = 0;
+    if (t < kMomHist * 10) c.mom = fa.edge[(((size_t)ch * fa.n_wg + fa.n_wg - 1) * kEdgeRecs + 4) * 10 + t];
     if (t < kCicHist)
-        reinterpret_cast<uint32_t *>(fa.hist_cic)[(size_t)ch * kCicHist + t] = cic32[n_blk - kCicHist + t];
-    uint32_t *he = reinterpret_cast<uint32_t *>(fa.hist_comp) + (size_t)ch * kCompHist;
-    uint32_t v;
-    if (nf >= (uint32_t)kCompHist || t >= kCompHist - nf) v = fa.comp_tail[(size_t)ch * kCompHist + t];
-    else v = he[t + nf];
-    __syncthreads(); // a short call shifts the old history in place
-    he[t] = v;
-    if (t < 6) fa.carry_saved[ch * 6 + t] = fa.carry_work[ch * 6 + t];
-    if (t == 0) fa.acc0[ch] += fa.samples_lo * fa.phi32v[ch];
+        c.cic = reinterpret_cast<const uint32_t *>(fa.cic)[(size_t)ch * (kCicHist + n_blk) + kCicHist + n_blk - kCicHist + t];
+    if (t < 6) c.carry = fa.carry_work[ch * 6 + t];
+    if (t == 0) c.phase = fa.acc0[ch] + fa.samples_lo * fa.phi32v[ch];
+}
+// comp: entry t of the new compensator history (frame nf - 256 + t of the call, or of what came before it)
+__device__ __forceinline__ void rx_channel_store(const RxFused &fa, uint32_t ch, uint32_t t, const ChannelCarry &c, uint32_t comp)
+{
+    if (t < kMomHist * 10) fa.hist_mom[(size_t)ch * kMomHist * 10 + t] = c.mom;
+    if (t < kCicHist) reinterpret_cast<uint32_t *>(fa.hist_cic)[(size_t)ch * kCicHist + t] = c.cic;
+    reinterpret_cast<uint32_t *>(fa.hist_comp)[(size_t)ch * kCompHist + t] = comp;
+    if (t < 6) fa.carry_saved[ch * 6 + t] = c.carry;
+    if (t == 0) fa.acc0[ch] = c.phase;
 }
 
 // After the sample loop of ddc_rx_front_cic: thread t holds the moments of window b = 256 k + t of
@@ -1018,12 +1058,24 @@ __global__ __launch_bounds__(256) void ddc_rx_tail(uint32_t n_blk, const RxFused
 {
     __shared__ __align__(16) char lds[kLdsFlag + 16];
     const uint32_t t = threadIdx.x, ch = blockIdx.x / fa.n_tiles, j = blockIdx.x - ch * fa.n_tiles;
+    const uint32_t nf = n_blk / 2;
+    ChannelCarry carry;
+    if (fa.n_tiles == 1) {
+        // the only tile of its channel: it saves the state itself, everything it needs for that is at hand
+        rx_channel_load(fa, ch, n_blk, t, carry);
+        rx_tile_finish(fa, ch, j, n_blk, lds, t);
+        // frame nf - 256 + t is Hilbert tile sample nf - 1 + t (history included when the call is shorter than 256 frames)
+        const uint32_t ci = (uint16_t)reinterpret_cast<const int16_t *>(lds + kLdsXs)[nf - 1 + t];
+        const uint32_t cq = (uint16_t)reinterpret_cast<const int16_t *>(lds + kLdsCq)[nf + t];
+        rx_channel_store(fa, ch, t, carry, ci | (cq << 16));
+        return;
+    }
     rx_tile_finish(fa, ch, j, n_blk, lds, t);
     uint32_t *flag = reinterpret_cast<uint32_t *>(lds + kLdsFlag);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores of comp_tail have landed
     __syncthreads();
     if (t == 0) {
-        const uint32_t last = fa.n_tiles > 1 ? (count_in(fa.chan_cnt + ch, fa.n_tiles) ? 1u : 0u) : 1u;
+        const uint32_t last = count_in(fa.chan_cnt + ch, fa.n_tiles) ? 1u : 0u;
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1031,7 +1083,9 @@ __global__ __launch_bounds__(256) void ddc_rx_tail(uint32_t n_blk, const RxFused
         flag[0] = last;
     }
     __syncthreads();
-    if (flag[0]) rx_channel_finish(fa, ch, n_blk, t);
+    if (!flag[0]) return;
+    rx_channel_load(fa, ch, n_blk, t, carry);
+    rx_channel_store(fa, ch, t, carry, fa.comp_tail[(size_t)ch * kCompHist + t]);
 }
 
 /*
@@ -1153,7 +1207,9 @@ __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict_
 {
     __shared__ __align__(16) uint32_t xs[2][kHilbIn / 2]; // [0]: pairs (2m, 2m+1), [1]: pairs (2m+1, 2m+2)
     __shared__ uint32_t p0[kHilbIn / 32 + 2], p1[kHilbIn / 32 + 2];
+    __shared__ __align__(16) uint32_t taps[144];
     const uint32_t ch = blockIdx.x / tiles, n0 = (blockIdx.x - ch * tiles) * (uint32_t)kTailTile, t = threadIdx.x;
+    hilbert_stage_taps(taps, t);
     const uint32_t *x = reinterpret_cast<const uint32_t *>(comp) + (size_t)ch * (kCompHist + nf);
     const uint32_t last = kCompHist + nf - 1;
     int16_t *sa = reinterpret_cast<int16_t *>(xs[0]), *sb = reinterpret_cast<int16_t *>(xs[1]);
@@ -1172,7 +1228,7 @@ __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict_
     __syncthreads();
     const uint32_t par = t >> 7, g = t & 127u;
     int S[4];
-    hilbert_quad_sums(reinterpret_cast<const uint4 *>(&xs[0][0]) + par * (kHilbIn / 8) + g, S);
+    hilbert_quad_sums(reinterpret_cast<const uint4 *>(&xs[0][0]) + par * (kHilbIn / 8) + g, taps, S);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
