@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-copy-rate", action="store_true", help="skip the device-to-device copy rate in the roofline block")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the config-3 (ddc+fft) and config-4 (tx) shapes that the default run times after the headline")
     ap.add_argument("--shared-stream", action="store_true",
                     help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
                          "reported apart from the headline: the ADC bytes then come from L2, not HBM")
@@ -263,10 +265,40 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.workload == "tx":
+        res = bench_tx(args, dev, local_rank, rank, world, dist)
+    else:
+        res = bench_rx(args, dev, local_rank, rank, world, dist, do_gather)
+        if rank == 0 and world == 1 and args.workload == "ddc" and not args.no_secondary and not args.shared_stream:
+            # BASELINE configs 3 and 4 at their shapes, a few steps each, timed by this same run
+            sec = {}
+            a3 = argparse.Namespace(**vars(args))
+            a3.workload, a3.channels, a3.samples, a3.steps, a3.warmup = "ddc+fft", 256, 1 << 22, 5, 2
+            a3.no_cpu_baseline = a3.no_copy_rate = True
+            r3 = bench_rx(a3, dev, local_rank, rank, world, None, False)
+            a4 = argparse.Namespace(**vars(a3))
+            a4.workload = "tx"
+            r4 = bench_tx(a4, dev, local_rank, rank, world, None)
+            for name, r in (("config3", r3), ("config4", r4)):
+                sec[name] = {"workload": r["config"]["workload"], "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                             "steps": r["steps"], "ms_per_step": r["ms_per_step"], "frac": r["roofline"]["frac"],
+                             "frac_of_step": r["roofline"]["frac_of_step"], "kernel": r["roofline"]["kernel"],
+                             "parity_check": r["config"]["parity_check"]}
+            res["secondary"] = sec
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
+    """The RX chain (and, for ddc+fft, the panadapter rows) over resident ADC rows; returns the result dict on rank 0."""
+    import numpy as np
+    import torch
     import ua3reo_ddc
     from ua3reo_ddc import shard
-    if args.workload == "tx":
-        return bench_tx(args, dev, local_rank, rank, world, dist)
     nch, S = args.channels, args.samples
     assert S % 1024 == 0
     nf = S // 1024
@@ -381,20 +413,28 @@ def main(argv=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    res = None
     if rank == 0:
         units = float(world) * nch * S * args.steps  # channel-samples ingested by the whole job
         value = units / dt / 1e6
         front_avg_ms = front_ms / max(1, ncalls)
+        two_kernels = args.rx_plan == "auto" and (S // 512) % 256 == 0
+        kernel_name = "ddc_rx_front_cic" if two_kernels else "ddc_rx_front"
         achieved = BYTES_PER_CHANNEL_SAMPLE * nch * S / (front_avg_ms * 1e-3) / 1e9
         traffic = None if shared else load_profile("traffic.json", nch, S)
         valu = None if shared else load_profile("valu.json", nch, S)
+        step_ms = dt / args.steps * 1e3
         roof = {
-            "bound": "hbm",
-            "kernel": "ddc_rx_front",
+            # the fraction is quoted against the HBM peak; what holds the kernel back is named below
+            # once the vector-ALU counters of this kernel source are at hand
+            "bound": "unknown (no vector-ALU counter pass on this kernel source; fraction quoted against the HBM peak)",
+            "kernel": kernel_name,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # the same algorithmic bytes over the whole step (every kernel of the call and the gaps between them)
+            "frac_of_step": round(BYTES_PER_CHANNEL_SAMPLE * nch * S / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": float(traffic["traffic_bytes"]) if traffic else None,
             "traffic_source": ("%s @ commit %s" % (traffic["source"], traffic.get("commit", "?"))) if traffic else
                               "no PMC pass on this kernel source and shape in profiles/",
@@ -442,6 +482,8 @@ def main(argv=None):
                     "hbm_frac_at_issue_roof": round(BYTES_PER_CHANNEL_SAMPLE * nch * S / roof_mx / 1e9 / HBM_PEAK_GBS, 4),
                 }
             roof["closer_roof"] = "valu-issue" if need / have > achieved / HBM_PEAK_GBS else "hbm"
+            roof["bound"] = "hbm" if roof["closer_roof"] == "hbm" else \
+                "valu-issue (vector-ALU instruction issue; fraction quoted against the HBM peak)"
         res = {
             "metric": METRIC,
             "value": round(value, 1),
@@ -485,12 +527,9 @@ def main(argv=None):
             v, one, used, sample = cpu_baseline(threads)
             res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": used,
                                    "kind": "port", "sample": sample, "one_thread": round(one, 1)}
-        print(json.dumps(res), flush=True)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0
+    del adc, outs
+    return res if rank == 0 else None
 
 
 def bench_tx(args, dev, local_rank, rank, world, dist):
@@ -553,6 +592,7 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    res = None
     if rank == 0:
         bytes_per = 2.0 + 4.0 / 1024.0
         achieved = bytes_per * nch * S / (call_ms * 1e-3) / 1e9
@@ -568,15 +608,13 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
                        "channels_per_gpu": nch, "parity_check": check},
             "roofline": {"bound": "hbm", "kernel": "whole ddc_tx_process_dev call (ddc_tx_duc dominates)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "avg_launch_ms": round(call_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_of_step": round(bytes_per * nch * S / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "avg_launch_ms": round(call_ms, 4)},
         }
-        print(json.dumps(res), flush=True)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0
+    del iq, dac
+    return res if rank == 0 else None
 
 
 if __name__ == "__main__":
