@@ -249,7 +249,7 @@ def main(argv=None):
     import numpy as np
     import torch
     do_gather = world > 1 or args.force_gather
-    if do_gather:
+    if world > 1:
         import torch.distributed as dist
         # stdout carries the one JSON line: RCCL's own banner / debug text goes to stderr
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
@@ -327,24 +327,34 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     # [buffer][SPEC|VOICE][channel][frame][I,Q]; two buffers so that the gather of step k
     # overlaps the compute of step k+1 (ua3reo_ddc/shard.py, StepGather)
+    outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
+    gathered = None
     if do_gather:
-        sg = shard.StepGather(dist, (2, nch, nf, 2), torch.int16, dev, compute_stream=ext, timed=True)
-        outs = sg.outs
-    else:
-        sg = None
-        outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
+        # the library's own collective (ddc_allgather_decimated_dev: one ncclAllGather of bytes on a second
+        # stream, two slots); the communicator id travels over torch.distributed, which the ranks have anyway
+        gathered = torch.zeros((2, world, 2, nch, nf, 2), dtype=torch.int16, device=dev)
+        if world > 1:
+            box = [ua3reo_ddc.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm_id = box[0]
+        else:
+            comm_id = ua3reo_ddc.comm_unique_id()
+        with _StdoutToStderr():
+            ctx.comm_init(world, rank, comm_id)
     step_no = [0]
     torch.cuda.synchronize()
 
     def step():
         k = step_no[0]
         step_no[0] += 1
-        o = sg.buffer(k) if sg else outs[k & 1]
+        o = outs[k & 1]
+        if do_gather:
+            ctx.allgather_reuse(k & 1)  # the gather of step k - 2 has read this buffer
         ctx.rx_process_dev(adc.data_ptr(), pitch, S, o[0].data_ptr(), o[1].data_ptr())
         if with_fft:
             ctx.fft_process_dev(o[0].data_ptr(), nf, fft_bins.data_ptr(), fft_rows.data_ptr())
-        if sg:
-            sg.submit(k)
+        if do_gather:
+            ctx.allgather_decimated_dev(k & 1, o.data_ptr(), nf, gathered[k & 1].data_ptr())
 
     # parity spot check before any timing: first call from power-on state vs the oracle
     check = "skipped"
@@ -386,9 +396,8 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     for _ in range(args.warmup):
         step()
     ctx.sync()
-    if sg:
-        sg.finish()
-        sg.times.clear()
+    if do_gather:
+        ctx.allgather_wait(-1)
     torch.cuda.synchronize()
     ctx.profile_enable(True)
     if dist is not None:
@@ -398,8 +407,9 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     for _ in range(args.steps):
         step()
     ctx.sync()
-    if sg:
-        sg.finish()
+    gather_ms = []
+    if do_gather:
+        gather_ms = [ctx.allgather_wait(b) for b in range(min(2, args.steps))]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -516,11 +526,16 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
             },
             "roofline": roof,
         }
-        if sg and sg.times:
-            g_ms = sg.average_ms()
-            res["config"]["all_gather"] = {"avg_ms": round(g_ms, 4), "bytes_per_rank": int(outs[0].numel() * 2),
+        if gather_ms:
+            g_ms = sum(gather_ms) / len(gather_ms)
+            k_last = step_no[0] - 1
+            ok = bool(torch.equal(gathered[k_last & 1][rank], outs[k_last & 1]))
+            res["config"]["all_gather"] = {"avg_ms": round(g_ms, 4), "of": "the last %d gathers" % len(gather_ms),
+                                           "bytes_per_rank": int(outs[0].numel() * 2),
                                            "share_of_step": round(g_ms / (dt / args.steps * 1e3), 4),
-                                           "note": "on a second stream, overlapped with the next step's compute"}
+                                           "own_shard_in_gathered": ok,
+                                           "note": "ddc_allgather_decimated_dev: ncclAllGather on a second stream, "
+                                                   "overlapped with the next step's compute"}
         if not args.no_cpu_baseline and world == 1:
             want = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1)
             threads = max(1, min(want, os.cpu_count() or 1))
@@ -528,7 +543,7 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
             res["cpu_baseline"] = {"value": round(v, 1), "unit": "MS/s", "cores": used,
                                    "kind": "port", "sample": sample, "one_thread": round(one, 1)}
     ctx.close()
-    del adc, outs
+    del adc, outs, gathered
     return res if rank == 0 else None
 
 

@@ -136,6 +136,41 @@ int ddc_tx_process(ddc_ctx *ctx, const int16_t *iq48k, size_t n_iq, uint16_t *da
 int ddc_tx_reset(ddc_ctx *ctx, int32_t channel);
 int ddc_tx_set_phase(ddc_ctx *ctx, int32_t channel, uint32_t phase22);
 
+/* Multi-GPU.  Channels are independent, so a job shards them over GPUs (one process and one
+ * ctx per GPU, contiguous channel ranges) and nothing is exchanged inside the chain; the one
+ * collective is the all-gather of the decimated outputs, the stream the reference sends over its
+ * 8-bit bus to the consumer of STM32/Src/fpga.c:286-401, here delivered to every rank.  No
+ * counterpart in the reference (one FPGA, one MCU).
+ *
+ * ddc_shard_range: the channels [*lo, *hi) of `rank` out of `world` ranks; the first
+ * total_channels % world ranks hold one more.
+ * ddc_comm_unique_id / ddc_comm_init: an RCCL communicator over `world` ranks for this ctx's
+ * GPU (ncclGetUniqueId on one rank, the 128 bytes carried to the others by the host, then
+ * ncclCommInitRank on every rank: a collective call).  ddc_comm_attach uses a communicator the
+ * host already owns (an ncclComm_t of the RCCL instance loaded in this process; the ctx does not
+ * destroy it).  RCCL is bound when one of these is first called (librccl.so.1); -ENOSYS when it
+ * cannot be loaded.
+ * ddc_allgather_decimated_dev: all-gather of this rank's decimated outputs, local =
+ * [2 (SPEC, VOICE)][n_channels][n_frames][2] int16 in one piece (e.g. the two output buffers of
+ * ddc_rx_process_dev allocated back to back), into gathered = [world][2][n_channels][n_frames][2]
+ * on every rank (device pointers; every rank must hold the same n_channels and pass the same
+ * n_frames).  One ncclAllGather of bytes on a stream of the ctx's own, started after the work
+ * queued on the ctx stream so far, so it overlaps whatever the ctx is given next.  Two slots for
+ * double buffering: step k computes into buffer k & 1 and gathers with slot k & 1;
+ * ddc_allgather_reuse(slot) makes the ctx stream wait for that slot's last gather, call it
+ * before queueing the work that overwrites the slot's `local` buffer; ddc_allgather_wait(slot)
+ * waits on the host until `gathered` of that slot is complete (-1: both) and reports the
+ * duration of the last gather waited for in milliseconds (gather_ms may be NULL). */
+#define DDC_COMM_ID_BYTES 128
+void ddc_shard_range(uint32_t rank, uint32_t world, uint32_t total_channels, uint32_t *lo, uint32_t *hi);
+int ddc_comm_unique_id(uint8_t id[DDC_COMM_ID_BYTES]);
+int ddc_comm_init(ddc_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t id[DDC_COMM_ID_BYTES]);
+int ddc_comm_attach(ddc_ctx *ctx, void *rccl_comm, uint32_t world, uint32_t rank);
+int ddc_comm_destroy(ddc_ctx *ctx);
+int ddc_allgather_decimated_dev(ddc_ctx *ctx, int slot, const int16_t *local, size_t n_frames, int16_t *gathered);
+int ddc_allgather_reuse(ddc_ctx *ctx, int slot);
+int ddc_allgather_wait(ddc_ctx *ctx, int slot, float *gather_ms);
+
 /* Wait for everything queued on the ctx stream. */
 int ddc_sync(ddc_ctx *ctx);
 /* The HIP stream of the ctx (a hipStream_t), for callers that time or chain work. */

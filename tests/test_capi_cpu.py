@@ -201,3 +201,19 @@ def test_oracle_usb_frames_known_answers(orc):
     g = np.float32(np.float32(1.0) / np.float32(30)) * np.float32(100)
     assert list(orc.usb_frames(x[:6], 30)) == [((int(np.float32(v) * g) + 32768) % 65536) - 32768 for v in x[:6]]
     assert list(orc.usb_frames(np.array([0, 5, -5], np.int32), 0)) == [0, -1, 0]   # 0 * inf = NaN -> 0; +-inf saturate
+
+
+def test_shard_range_is_the_host_logic_of_the_gloo_tests(ddc):
+    """ddc_shard_range (what a C host partitions with) = ua3reo_ddc.shard.channel_range (what the
+    gloo tests and the benchmark partition with): contiguous, covering, first ranks one larger."""
+    from ua3reo_ddc import shard
+    for world in (1, 2, 3, 8):
+        for total in (0, 1, 7, 8, 1023, 8192):
+            at = 0
+            for r in range(world):
+                lo, hi = ddc.shard_range(r, world, total)
+                assert (lo, hi) == shard.channel_range(r, world, total)
+                assert lo == at
+                at = hi
+            assert at == total
+    assert ddc.shard_range(3, 3, 10) == (0, 0)  # rank out of range: empty

@@ -3,6 +3,8 @@
  * tuning, kernel launches, bus-frame helpers.
  */
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <cerrno>
 #include <cmath>
@@ -78,6 +80,14 @@ struct ddc_ctx {
     size_t fft_work_cap = 0;           // floats per channel and branch d_fft_work holds
     void *d_stage[3] = {nullptr, nullptr, nullptr}; // host-pointer entry points
     size_t stage_cap[3] = {0, 0, 0};
+    // multi-GPU: the RCCL communicator of this rank and the all-gather of the decimated outputs, which runs on
+    // a stream of its own, ordered against the ctx stream by events (two slots: double buffering)
+    ncclComm_t comm = nullptr;
+    bool comm_owned = false;
+    uint32_t comm_world = 0, comm_rank = 0;
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_computed[2] = {}, ev_gather0[2] = {}, ev_gathered[2] = {};
+    bool gather_pending[2] = {false, false};
     // optional per-call timing: HIP events on the ctx stream around the front
     // kernel and around the whole RX call
     bool profile = false;
@@ -567,6 +577,7 @@ void ddc_destroy(ddc_ctx *ctx)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     ddc_tx_state_destroy(&ctx->tx);
+    (void)ddc_comm_destroy(ctx);
     for (auto &e3 : ctx->ev)
         for (auto &e : e3)
             if (e) (void)hipEventDestroy(e);
@@ -877,6 +888,194 @@ int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples)
                                   (size_t)(ddc::kCicHist + n_blk) * 4, (size_t)n_blk * 4, ctx->cfg.n_channels,
                                   hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+/* ---- multi-GPU: channel shards and the all-gather of the decimated outputs ---- */
+
+void ddc_shard_range(uint32_t rank, uint32_t world, uint32_t total_channels, uint32_t *lo, uint32_t *hi)
+{
+    uint32_t a = 0, b = 0;
+    if (world && rank < world) {
+        const uint32_t base = total_channels / world, extra = total_channels % world;
+        a = rank * base + std::min(rank, extra);
+        b = a + base + (rank < extra ? 1u : 0u);
+    }
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+}
+
+extern "C++" {
+namespace {
+// RCCL is bound at first use, by soname: a process that already has an RCCL loaded (PyTorch brings its own)
+// gets that instance, so that communicators and the HIP runtime under them are the process's one set.
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+RcclApi *rccl_api(ddc_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.AllGather) return &g_rccl;
+    if (!g_rccl.handle) {
+        for (const char *name : { "librccl.so.1", "librccl.so" }) {
+            g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.handle) break;
+        }
+        if (!g_rccl.handle) {
+            const char *e = dlerror();
+            fail(ctx, -ENOSYS, std::string("RCCL is not loadable: ") + (e ? e : "dlopen failed"));
+            return nullptr;
+        }
+    }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.handle, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
+    auto ag = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GetErrorString || !ag) {
+        fail(ctx, -ENOSYS, "the RCCL library lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather");
+        return nullptr;
+    }
+    g_rccl.AllGather = ag;
+    return &g_rccl;
+}
+
+int gather_resources(ddc_ctx *ctx)
+{
+    if (ctx->gather_stream) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
+    for (int s = 0; s < 2; s++) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_computed[s], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev_gather0[s]));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev_gathered[s]));
+    }
+    return 0;
+}
+} // namespace
+} // extern "C++"
+
+#define RCCL_TRY(ctx, api, call)                                                                   \
+    do {                                                                                           \
+        ncclResult_t r_ = (call);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(ctx, -EIO, std::string(#call) + ": " + (api)->GetErrorString(r_));         \
+    } while (0)
+
+int ddc_comm_unique_id(uint8_t id[DDC_COMM_ID_BYTES])
+{
+    static_assert(DDC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "communicator id size");
+    if (!id) return -EINVAL;
+    RcclApi *api = rccl_api(nullptr);
+    if (!api) return -ENOSYS;
+    ncclUniqueId u;
+    RCCL_TRY(nullptr, api, api->GetUniqueId(&u));
+    memcpy(id, u.internal, DDC_COMM_ID_BYTES);
+    return 0;
+}
+
+int ddc_comm_init(ddc_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t id[DDC_COMM_ID_BYTES])
+{
+    if (!ctx || !id) return -EINVAL;
+    if (world == 0 || rank >= world) return fail(ctx, -EINVAL, "ddc_comm_init: rank must be below world");
+    if (ctx->comm) return fail(ctx, -EBUSY, "this ctx already has a communicator");
+    RcclApi *api = rccl_api(ctx);
+    if (!api) return -ENOSYS;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, DDC_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    RCCL_TRY(ctx, api, api->CommInitRank(&c, (int)world, u, (int)rank));
+    ctx->comm = c;
+    ctx->comm_owned = true;
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return gather_resources(ctx);
+}
+
+int ddc_comm_attach(ddc_ctx *ctx, void *rccl_comm, uint32_t world, uint32_t rank)
+{
+    if (!ctx || !rccl_comm) return -EINVAL;
+    if (world == 0 || rank >= world) return fail(ctx, -EINVAL, "ddc_comm_attach: rank must be below world");
+    if (ctx->comm) return fail(ctx, -EBUSY, "this ctx already has a communicator");
+    if (!rccl_api(ctx)) return -ENOSYS;
+    ctx->comm = static_cast<ncclComm_t>(rccl_comm);
+    ctx->comm_owned = false;
+    ctx->comm_world = world;
+    ctx->comm_rank = rank;
+    return gather_resources(ctx);
+}
+
+int ddc_comm_destroy(ddc_ctx *ctx)
+{
+    if (!ctx) return -EINVAL;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->gather_stream) (void)hipStreamSynchronize(ctx->gather_stream);
+    if (ctx->comm && ctx->comm_owned && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_owned = false;
+    ctx->comm_world = ctx->comm_rank = 0;
+    for (int s = 0; s < 2; s++) {
+        for (hipEvent_t *e : { &ctx->ev_computed[s], &ctx->ev_gather0[s], &ctx->ev_gathered[s] })
+            if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        ctx->gather_pending[s] = false;
+    }
+    if (ctx->gather_stream) { (void)hipStreamDestroy(ctx->gather_stream); ctx->gather_stream = nullptr; }
+    return 0;
+}
+
+int ddc_allgather_decimated_dev(ddc_ctx *ctx, int slot, const int16_t *local, size_t n_frames, int16_t *gathered)
+{
+    if (!ctx) return -EINVAL;
+    if (slot != 0 && slot != 1) return fail(ctx, -EINVAL, "ddc_allgather_decimated_dev: slot is 0 or 1");
+    if (!local || !gathered) return fail(ctx, -EINVAL, "null buffer");
+    if (!ctx->comm) return fail(ctx, -ENOTCONN, "no communicator: call ddc_comm_init or ddc_comm_attach first");
+    RcclApi *api = rccl_api(ctx);
+    if (!api) return -ENOSYS;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    // SPEC block then VOICE block of this rank, [2][n_channels][n_frames][2] int16, sent as bytes
+    const size_t bytes = (size_t)2 * ctx->cfg.n_channels * n_frames * 2 * sizeof(int16_t);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_computed[slot], ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->gather_stream, ctx->ev_computed[slot], 0));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_gather0[slot], ctx->gather_stream));
+    RCCL_TRY(ctx, api, api->AllGather(local, gathered, bytes, ncclUint8, ctx->comm, ctx->gather_stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_gathered[slot], ctx->gather_stream));
+    ctx->gather_pending[slot] = true;
+    return 0;
+}
+
+int ddc_allgather_reuse(ddc_ctx *ctx, int slot)
+{
+    if (!ctx) return -EINVAL;
+    if (slot != 0 && slot != 1) return fail(ctx, -EINVAL, "ddc_allgather_reuse: slot is 0 or 1");
+    if (!ctx->gather_pending[slot]) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gathered[slot], 0));
+    return 0;
+}
+
+int ddc_allgather_wait(ddc_ctx *ctx, int slot, float *gather_ms)
+{
+    if (!ctx) return -EINVAL;
+    if (slot < -1 || slot > 1) return fail(ctx, -EINVAL, "ddc_allgather_wait: slot is 0, 1 or -1");
+    if (gather_ms) *gather_ms = 0.0f;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    for (int s = 0; s < 2; s++) {
+        if ((slot >= 0 && s != slot) || !ctx->gather_pending[s]) continue;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_gathered[s]));
+        if (gather_ms && s == (slot < 0 ? 1 : slot)) HIP_TRY(ctx, hipEventElapsedTime(gather_ms, ctx->ev_gather0[s], ctx->ev_gathered[s]));
+    }
+    if (gather_ms && slot < 0 && !ctx->gather_pending[1] && ctx->gather_pending[0])
+        HIP_TRY(ctx, hipEventElapsedTime(gather_ms, ctx->ev_gather0[0], ctx->ev_gathered[0]));
     return 0;
 }
 

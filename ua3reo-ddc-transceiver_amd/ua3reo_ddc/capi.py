@@ -82,6 +82,15 @@ def lib():
     L.ddc_rx_process.argtypes = [vp, vp, sz, sz, vp, vp]
     L.ddc_rx_read_cic.argtypes = [vp, vp, sz]
     L.ddc_debug_rx_plan.argtypes = [vp, C.c_int]
+    L.ddc_shard_range.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.ddc_shard_range.restype = None
+    L.ddc_comm_unique_id.argtypes = [vp]
+    L.ddc_comm_init.argtypes = [vp, u32, u32, vp]
+    L.ddc_comm_attach.argtypes = [vp, vp, u32, u32]
+    L.ddc_comm_destroy.argtypes = [vp]
+    L.ddc_allgather_decimated_dev.argtypes = [vp, C.c_int, vp, sz, vp]
+    L.ddc_allgather_reuse.argtypes = [vp, C.c_int]
+    L.ddc_allgather_wait.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.ddc_tx_process_dev.argtypes = [vp, vp, sz, vp]
     L.ddc_tx_process.argtypes = [vp, vp, sz, vp]
     L.ddc_tx_reset.argtypes = [vp, i32]
@@ -294,6 +303,26 @@ class Ddc:
         """0: call plan by size (one kernel when samples / 512 is a multiple of 256); 1: always the separate kernels."""
         self._check(self._L.ddc_debug_rx_plan(self._h, int(plan)))
 
+    def comm_init(self, world, rank, comm_id):
+        """Collective: builds this ctx's RCCL communicator from the 128-byte id of comm_unique_id() (the same on every rank)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(comm_id))
+        self._check(self._L.ddc_comm_init(self._h, world, rank, buf))
+
+    def comm_destroy(self):
+        self._check(self._L.ddc_comm_destroy(self._h))
+
+    def allgather_decimated_dev(self, slot, local_ptr, n_frames, gathered_ptr):
+        self._check(self._L.ddc_allgather_decimated_dev(self._h, slot, local_ptr, n_frames, gathered_ptr))
+
+    def allgather_reuse(self, slot):
+        self._check(self._L.ddc_allgather_reuse(self._h, slot))
+
+    def allgather_wait(self, slot=-1):
+        """Host wait for slot's gather (-1: both); returns the duration in ms of the last gather waited for."""
+        ms = C.c_float(0)
+        self._check(self._L.ddc_allgather_wait(self._h, slot, C.byref(ms)))
+        return ms.value
+
     def tx_process(self, iq48k):
         """Host path. iq48k: int16 [n_channels][n][2]; returns uint16 [n_channels][1024 n]."""
         a = np.ascontiguousarray(iq48k, dtype=np.int16)
@@ -437,6 +466,22 @@ class Ddc:
 
     def stream(self):
         return self._L.ddc_stream(self._h)
+
+
+def shard_range(rank, world, total_channels):
+    """[lo, hi) of the channels `rank` owns (ddc_shard_range)."""
+    lo, hi = C.c_uint32(0), C.c_uint32(0)
+    lib().ddc_shard_range(rank, world, total_channels, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def comm_unique_id():
+    """128 bytes that name a new RCCL communicator: taken on one rank, handed to every rank's Ddc.comm_init."""
+    buf = (C.c_uint8 * 128)()
+    rc = lib().ddc_comm_unique_id(buf)
+    if rc != 0:
+        raise DdcError("ddc_comm_unique_id failed (%d): %s" % (rc, (lib().ddc_last_error(None) or b"").decode()))
+    return bytes(buf)
 
 
 def pack_adc12(samples):
