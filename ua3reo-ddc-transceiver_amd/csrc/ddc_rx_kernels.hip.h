@@ -852,13 +852,31 @@ __device__ __forceinline__ void rx_front_body(
 
     const uint32_t tid = threadIdx.x;
     const uint32_t g0 = blockIdx.x * kFrontThreads;
-    for (uint32_t i = tid; i < 2048; i += kFrontThreads) tab[i] = nco_tab[i];
+    const uint32_t lane = tid & 63u, wave_base = tid & ~63u;
+    // the coarse NCO table: 16 KB straight into LDS, 1 KB per wave and load (waited for with the first line)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        lds_dma16(reinterpret_cast<const uint8_t *>(nco_tab) + (i * kFrontThreads + tid) * 16u,
+                  reinterpret_cast<uint4 *>(tab) + i * kFrontThreads + wave_base);
 
     // staging sources: load j of a wave covers rows wave_base + 8 j .. + 7, lane l
     // fetching for row 8 j + (l >> 3) the piece that lives in slot l & 7
-    const uint32_t lane = tid & 63u, wave_base = tid & ~63u;
     const uint8_t *src[8];
-    {
+    uint32_t ch, b;
+    bool active = true;
+    if (FUSED) {
+        // the 256 windows of the workgroup lie one behind the other in one channel's row
+        const uint32_t ch_u = blockIdx.x / fa.n_wg, k_u = blockIdx.x - ch_u * fa.n_wg;
+        const uint8_t *wg_rows = adc + (size_t)ch_u * row_bytes + (size_t)k_u * (kFrontThreads * kBlkBytes);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t row = wave_base + 8u * j + (lane >> 3);
+            const uint32_t piece = (lane & 7u) ^ line_swz(row);
+            src[j] = wg_rows + (row * (uint32_t)kBlkBytes + piece * 16u);
+        }
+        ch = ch_u;
+        b = k_u * kFrontThreads + tid;
+    } else {
         uint32_t go = g0 + wave_base + (lane >> 3);
         go = go < total_blocks ? go : total_blocks - 1;
         uint32_t cho = go / n_blk, bo = go - cho * n_blk;
@@ -874,12 +892,12 @@ __device__ __forceinline__ void rx_front_body(
                 while (bo >= n_blk) { bo -= n_blk; cho++; }
             }
         }
+        const uint32_t g = g0 + tid;
+        active = g < total_blocks;
+        const uint32_t gc = active ? g : total_blocks - 1;
+        ch = gc / n_blk;
+        b = gc - ch * n_blk;
     }
-
-    const uint32_t g = g0 + tid;
-    const bool active = g < total_blocks;
-    const uint32_t gc = active ? g : total_blocks - 1;
-    const uint32_t ch = gc / n_blk, b = gc - ch * n_blk;
     // phase and increment come in shifted left by 10 (32-bit wrap = accumulator
     // wrap); the sample loop runs on the << 8 form nco_fetch wants
     const uint32_t phi_in = phi32v[ch];
@@ -894,8 +912,6 @@ __device__ __forceinline__ void rx_front_body(
     Cascade ci, cq;
     ci.clear();
     cq.clear();
-
-    __syncthreads(); // tab is ready
 
     // own row in the line buffer: piece p sits at mine ^ (p << 4) (byte address)
     const uint32_t mine = tid * 128u + (line_swz(tid) << 4);
