@@ -14,10 +14,13 @@
  *   FFT_doFFT + row mapping        STM32/Src/fft.c:212-331, :361-379, :506-539 (zoom branch :236-261)
  *   processTxAudio / ModulateFM    STM32/Src/audio_processor.c:61-273, :590-619
  *
- * All of it is recursion in time (IIR lattices, LMS, AGC, squelch), so the only
- * parallel axis is the channel: one thread walks one channel, block by block of
- * 192 frames, exactly in the firmware's order of operations.  Floating-point
- * contraction is off so that every operation rounds where the firmware's does.
+ * All of it is recursion in time (IIR lattices, LMS, AGC, squelch).  The RX path is cut
+ * where the recursions allow it: the lattice filters run as a systolic pipeline over the
+ * lanes of a wave (ddc_audio_rx_filters), the rest as one wave per channel with the
+ * element-wise work spread over the lanes (ddc_audio_rx_demod); the TX path and the
+ * panadapter prefilter walk one channel per lane (pair).  In every form a sample sees the
+ * firmware's operations in the firmware's order; floating-point contraction is off so
+ * that every operation rounds where the firmware's does.
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -268,7 +271,7 @@ __device__ __forceinline__ int32_t f2i_sat(float v)
 }
 
 // arm_iir_lattice_f32 step with the state and the coefficient tables in registers
-// (N is 6, 7 or 11; the arrays are sized for the longest filter)
+// (N is 6, 7 or 11; the arrays are sized for the longest filter): the TX path's form
 template <int N>
 __device__ __forceinline__ float lattice_reg(float (&g)[11], const float (&k)[11], const float (&v)[12], float x)
 {
@@ -292,63 +295,270 @@ __device__ __forceinline__ float lattice_reg(float (&g)[11], const float (&k)[11
 constexpr int kABiPitch = kABlock + 1; // LDS row pitch in floats: rows of neighbouring lanes start one bank apart
 
 /*
- * processRxAudio for every channel, sequential over the n_frames / 192 blocks of
- * the call.  spec_iq / voice_iq: [channel][n_frames][2] int16; audio:
- * [channel][n_frames][2] int32 (left = I, right = Q).
+ * The filter half of processRxAudio as a systolic pipeline: dc_filter, RF gain and the
+ * HPF / LPF lattices (audio_processor.c:299-362, :445-464) for every channel, results to
+ * filt[channel][frame] = {I, Q} floats for ddc_audio_rx_demod.
  *
- * A channel is a pair of neighbouring lanes: the I and the Q branch each run
- * their DC blocker, gain and lattice filters (most of the arithmetic, and the two
- * never meet before the demodulator) in a lane of their own and swap the
- * filtered sample with one DPP move.  From there on both lanes hold both values
- * and run the demodulator, notch and S-meter identically; the even lane alone
- * owns the shared state, the block-wise stages and the stores.
+ * An IIR lattice is a chain of stages: stage i of sample n needs f from stage i - 1 of the
+ * same sample and the g that stage i + 1 produced for sample n - 1.  So every stage gets a
+ * lane of its own, f and the running tap sum acc travel down the lanes (wave_shr:1), g travels
+ * up (wave_shl:1), and lane L works on item j = tick - L.  Items alternate between the two
+ * branches (j = 2 n + branch), which fills the tick a stage would otherwise wait for its g:
+ * every lane does useful work on every tick, and every sample sees exactly the operations of
+ * arm_iir_lattice_f32 in exactly their order.
  *
- * Everything that runs sample by sample in the firmware runs here in one pass
- * with its state in registers; the block of 192 demodulated samples that the
- * block-wise stages need (noise reduction, AGC peak and ramp, CW decoder) waits
- * in LDS.
+ * 20 lanes per channel, three channels per wave:
+ *   lane 0       source: int16 -> float, dc_filter (slots 0 / 1), RF gain
+ *   lanes 1..6   HPF stages 0..5, lane 7 its output tap (acc + f v[6]) -> the next filter's input
+ *   lanes 8..18  LPF stages (a 7-stage filter sits in lanes 12..18), lane 19 its output tap
+ * A filter that is off, and the unused lanes of a short one, pass f through.  Roles are data,
+ * not code: a pass lane is a stage with k = v = 0, an output tap a stage with k = 1 and no g
+ * from its neighbour, so one instruction stream serves all lanes.  The loop is unrolled over
+ * 32 ticks (16 frames): the source lane's input registers and lane 19's output registers are
+ * indexed statically.
  */
-__global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ states, uint32_t n_ch,
-                                                   const int16_t *__restrict__ spec_iq,
-                                                   const int16_t *__restrict__ voice_iq, uint32_t n_frames,
-                                                   int32_t *__restrict__ audio)
+constexpr int kFiltSeg = 20, kFiltPerWave = 3, kFiltTicks = 32;
+
+__device__ __forceinline__ float dpp_from_lower(float v)   // lane i <- lane i - 1
 {
-    __shared__ float blockbuf[32 * kABiPitch];
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ch = gid >> 1, q = gid & 1u; // q = 0: I branch and owner of the channel, 1: Q branch
-    if (ch >= n_ch) return;
-    const bool owner = q == 0;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_upper(float v)   // lane i <- lane i + 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+struct FiltLane {
+    float k, v;            // this lane's stage coefficients
+    bool use_nb;           // g comes from the lane above (a real stage)
+    bool is_fin, is_src, zero_acc;
+    float rf_gain;
+    uint32_t half_i, half_q; // bit offset of the I / Q half of a packed input word
+    uint32_t L;
+};
+
+// MODE 0: first iteration (lanes start one after the other), 1: steady state, 2: the last two
+// iterations (lanes stop one after the other; the g of the last I item is kept beside that of the last Q item)
+template <int MODE>
+__device__ __forceinline__ void filt_iteration(const FiltLane &ln, const uint4 (&in4)[4], uint32_t tick0, uint32_t items,
+                                               float &f_out, float &a_out, float &g_out, float &g_prev, float g_q_init,
+                                               float (&dx)[2], float (&dy)[2], float (&o)[32], float2 *dst, uint32_t frame0,
+                                               bool store_lane, bool do_store)
+{
+    const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
+                              in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
+    const float A1 = 0.99951171875f; // 1 - 2^-11
+#pragma unroll
+    for (int k = 0; k < kFiltTicks; k++) {
+        const float f_in = dpp_from_lower(f_out), a_in = dpp_from_lower(a_out), g_in = dpp_from_upper(g_out);
+        // one lattice stage (arm_iir_lattice_f32): fnext = f - k g; gnext = fnext k + g; acc += gnext v
+        const float g_use = ln.use_nb ? g_in : 0.0f;
+        const float kg = ln.k * g_use;
+        const float t = f_in - kg;
+        const float tk = t * ln.k;
+        const float gn = tk + g_use;
+        const float av = gn * ln.v;
+        const float as = a_in + av;
+        float nf = ln.is_fin ? as : t;
+        const float na = ln.zero_acc ? 0.0f : as;
+        // the source lane: item k of this iteration is frame k / 2, branch k & 1
+        const int br = k & 1;
+        const float x = (float)(int)__builtin_amdgcn_sbfe(in[k >> 1], br ? ln.half_q : ln.half_i, 16u);
+        const float d = x - dx[br];
+        const float a1y = A1 * dy[br];
+        const float y = d + a1y;
+        const float sv = y * ln.rf_gain;
+        nf = ln.is_src ? sv : nf;
+        bool act = true;
+        if (MODE == 0) act = (uint32_t)k >= ln.L;
+        if (MODE == 2) act = tick0 + (uint32_t)k - ln.L < items;
+        if (MODE == 1) {
+            dx[br] = x; dy[br] = y;
+            f_out = nf; a_out = na; g_out = gn;
+        } else {
+            if (act) {
+                dx[br] = x; dy[br] = y;
+                if (MODE == 2) g_prev = g_out;
+                f_out = nf; a_out = na; g_out = gn;
+            }
+            if (MODE == 0 && (uint32_t)(k + 1) == ln.L) g_out = g_q_init; // the lane above starts its Q item next
+        }
+        o[(k + 13) & 31] = f_out;
+        if (k == 18 && do_store && store_lane) {
+            // lane 19 has just finished the 32 items (16 frames) that started 32 ticks ago
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                reinterpret_cast<float4 *>(dst + frame0)[j] = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void ddc_audio_rx_filters(AudioState *__restrict__ states, uint32_t n_ch,
+                                                           const int16_t *__restrict__ spec_iq,
+                                                           const int16_t *__restrict__ voice_iq, uint32_t n_frames,
+                                                           float2 *__restrict__ filt)
+{
+    const uint32_t lane = threadIdx.x, seg = lane / kFiltSeg, L = lane - seg * kFiltSeg;
+    const uint32_t ch_raw = blockIdx.x * kFiltPerWave + seg;
+    const bool live = seg < (uint32_t)kFiltPerWave && ch_raw < n_ch;
+    const uint32_t ch = live ? ch_raw : 0;
     AudioState &s = states[ch];
-    float *bi = &blockbuf[(threadIdx.x >> 1) * kABiPitch];
     const ddc_audio_params p = s.p;
     const int m = p.mode;
     const bool use_spec = (m == DDC_MODE_IQ || m == DDC_MODE_NFM || m == DDC_MODE_WFM || m == DDC_MODE_AM);
+    const bool ssb = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_DIGI_L || m == DDC_MODE_USB ||
+                      m == DDC_MODE_CW_U || m == DDC_MODE_DIGI_U);
+    const bool hpf = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_USB || m == DDC_MODE_CW_U);
+    const bool chain = ssb || m == DDC_MODE_NFM || m == DDC_MODE_WFM || m == DDC_MODE_AM;
+    const bool lpf = chain && p.filter_width > 0;
+    const int lpf_n = s.lpf_n;
+
+    FiltLane ln;
+    ln.L = L;
+    ln.k = 0.0f; ln.v = 0.0f;
+    ln.use_nb = false; ln.is_fin = false;
+    ln.is_src = L == 0;
+    ln.rf_gain = p.rf_gain;
+    ln.half_i = p.iq_swap ? 16u : 0u;
+    ln.half_q = p.iq_swap ? 0u : 16u;
+    // which state slot this lane's g output feeds (the stage above it), -1: none
+    int provides = -1;
+    const float *g_i = nullptr, *g_q = nullptr;
+    if (live && hpf && L >= 1 && L <= 7) {
+        const int i = (int)L - 1; // 0..5: stage, 6: output tap
+        if (i < 6) { ln.k = ddc_hpf_k[s.hpf_idx][i]; ln.v = ddc_hpf_v[s.hpf_idx][i]; ln.use_nb = true; provides = i - 1; }
+        else { ln.k = 1.0f; ln.v = ddc_hpf_v[s.hpf_idx][6]; ln.is_fin = true; provides = 5; }
+        g_i = s.hpf_i.g; g_q = s.hpf_q.g;
+    }
+    if (live && lpf && L >= 8) {
+        const int i = (int)L - (19 - lpf_n); // 0..lpf_n-1: stage, lpf_n: output tap
+        if (i >= 0 && i < lpf_n) { ln.k = ddc_lpf_k[s.lpf_idx][i]; ln.v = ddc_lpf_v[s.lpf_idx][i]; ln.use_nb = true; provides = i - 1; }
+        else if (i == lpf_n) { ln.k = 1.0f; ln.v = ddc_lpf_v[s.lpf_idx][lpf_n]; ln.is_fin = true; provides = lpf_n - 1; }
+        g_i = s.lpf_i.g; g_q = s.lpf_q.g;
+    }
+    ln.zero_acc = ln.is_fin || ln.is_src;
+    float dx[2] = { s.dc_x[0], s.dc_x[1] }, dy[2] = { s.dc_y[0], s.dc_y[1] };
+    float g_out = provides >= 0 ? g_i[provides] : 0.0f;
+    const float g_q_init = provides >= 0 ? g_q[provides] : 0.0f;
+    float f_out = 0.0f, a_out = 0.0f, g_prev = 0.0f;
+    float o[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) o[i] = 0.0f;
+
     const uint32_t *src = reinterpret_cast<const uint32_t *>(use_spec ? spec_iq : voice_iq) + (size_t)ch * n_frames;
-    int32_t *dst = audio + (size_t)ch * n_frames * 2;
+    float2 *dst = filt + (size_t)ch * n_frames;
+    const bool src_lane = live && L == 0, store_lane = live && L == (uint32_t)kFiltSeg - 1;
+    const uint32_t G = n_frames / 16, items = 2 * n_frames; // n_frames is a multiple of 192
+    uint4 cur[4] = {}, nxt[4] = {};
+    if (src_lane) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = reinterpret_cast<const uint4 *>(src)[k];
+    }
+    for (uint32_t c = 0; c <= G; c++) {
+        if (src_lane && c + 1 < G) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) nxt[k] = reinterpret_cast<const uint4 *>(src + 16 * (c + 1))[k];
+        }
+        const uint32_t frame0 = c ? 16 * (c - 1) : 0;
+        if (c == 0)
+            filt_iteration<0>(ln, cur, 0, items, f_out, a_out, g_out, g_prev, g_q_init, dx, dy, o, dst, frame0, store_lane, false);
+        else if (c + 1 < G)
+            filt_iteration<1>(ln, cur, 32 * c, items, f_out, a_out, g_out, g_prev, g_q_init, dx, dy, o, dst, frame0, store_lane, true);
+        else
+            filt_iteration<2>(ln, cur, 32 * c, items, f_out, a_out, g_out, g_prev, g_q_init, dx, dy, o, dst, frame0, store_lane, true);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
+    if (!live) return;
+    if (L == 0) { s.dc_x[0] = dx[0]; s.dc_x[1] = dx[1]; s.dc_y[0] = dy[0]; s.dc_y[1] = dy[1]; }
+    if (provides >= 0) {
+        float *wi = L <= 7 ? s.hpf_i.g : s.lpf_i.g, *wq = L <= 7 ? s.hpf_q.g : s.lpf_q.g;
+        wi[provides] = g_prev;
+        wq[provides] = g_out;
+    }
+}
+
+/*
+ * arm_lms_norm_f32 (noise_reduction.c:19-37 through lms_block above) for one 64-sample
+ * sub-block with the sixteen taps in lanes 0..15: lane i holds w[i] and the sample px[i]
+ * the tap multiplies; the tap sum runs up the lanes one add at a time (lane i takes the sum
+ * of lane i - 1 and adds its own product, sixteen times, so it is the same left-to-right sum
+ * as the loop's), everything scalar in the firmware's loop is computed by every lane alike.
+ * x_reg / ref_reg: lane l holds input sample l / reference sample l of the sub-block;
+ * returns the filter output of sample l in lane l.  px of lanes 0..14 carries the fifteen
+ * past samples from sub-block to sub-block.
+ */
+__device__ __forceinline__ float lms_lanes(float x_reg, float ref_reg, float &w, float &px, float &energy, float &x0,
+                                           uint32_t lane)
+{
+    float out = 0.0f;
+    for (int t = 0; t < kASub; t++) {
+        const float in = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x_reg), t));
+        if (lane == 15) px = in;
+        energy -= x0 * x0;
+        energy += in * in;
+        const float prod = px * w;
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) // row_shr:1, lane 0 keeps 0: a(lane i) = a(lane i - 1) + prod(lane i)
+            a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xF, 0xF, false)) + prod;
+        const float acc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 15));
+        const float ref = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ref_reg), t));
+        const float e = ref - acc;
+        const float ws = (e * 0.000001f) / (energy + 0.000000119209289f);
+        const float wp = ws * px;
+        w += wp;
+        x0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), 0));
+        if (lane == (uint32_t)t) out = acc;
+        px = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, px), 0x101, 0xF, 0xF, false)); // lane i <- lane i + 1
+    }
+    return out;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+/*
+ * The rest of processRxAudio (audio_processor.c:308-435) on the filtered samples of
+ * ddc_audio_rx_filters, one wave per channel, block after block of 192 frames (three frames
+ * per lane).  Everything that is the same operation on every sample runs across the lanes
+ * (SSB sum / AM envelope / FM discriminator angle, S-meter and AGC peak searches, gain
+ * multiply, volume and integer conversion); the recursions (FM filters, notch biquad, AGC
+ * ramp) run as one loop over the block that every lane executes on the same values, each
+ * lane keeping the three results that are its own, so every sample still sees the firmware's
+ * operations in the firmware's order.  Noise reduction and the CW decoder keep their
+ * one-lane form.  filt: [channel][n_frames] {I, Q}; audio: [channel][n_frames][2] int32.
+ */
+__global__ __launch_bounds__(64) void ddc_audio_rx_demod(AudioState *__restrict__ states, uint32_t n_ch,
+                                                         const float2 *__restrict__ filt, uint32_t n_frames,
+                                                         int32_t *__restrict__ audio)
+{
+    __shared__ float bi[kABlock], bq[kABlock];
+    const uint32_t ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= n_ch) return;
+    AudioState &s = states[ch];
+    const ddc_audio_params p = s.p;
+    const int m = p.mode;
+    const float2 *src = filt + (size_t)ch * n_frames;
+    int2 *dst = reinterpret_cast<int2 *>(audio) + (size_t)ch * n_frames;
     const bool ssb_l = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_DIGI_L);
     const bool ssb_u = (m == DDC_MODE_USB || m == DDC_MODE_CW_U || m == DDC_MODE_DIGI_U);
-    const bool hpf = (m == DDC_MODE_LSB || m == DDC_MODE_CW_L || m == DDC_MODE_USB || m == DDC_MODE_CW_U);
     const bool fm = (m == DDC_MODE_NFM || m == DDC_MODE_WFM);
     const bool am = m == DDC_MODE_AM;
     const bool chain = ssb_l || ssb_u || fm || am;
-    const bool lpf = chain && p.filter_width > 0;
     const bool notch = chain && !fm && p.notch;
-    const int lpf_n = s.lpf_n;
     const float vol = p.mute ? 0.0f : (float)p.volume / 100.0f;
-    const float rf_gain = p.rf_gain;
-    const bool swap = p.iq_swap;
-    // coefficients and per-sample state into registers
-    float lk[11], lv[12], hk[11], hv[12];
-#pragma unroll
-    for (int i = 0; i < 11; i++) { lk[i] = ddc_lpf_k[s.lpf_idx][i]; hk[i] = i < 6 ? ddc_hpf_k[s.hpf_idx][i] : 0.0f; }
-#pragma unroll
-    for (int i = 0; i < 12; i++) { lv[i] = ddc_lpf_v[s.lpf_idx][i]; hv[i] = i < 7 ? ddc_hpf_v[s.hpf_idx][i] : 0.0f; }
-    float *hpf_g = q ? s.hpf_q.g : s.hpf_i.g, *lpf_g = q ? s.lpf_q.g : s.lpf_i.g;
-    float gh[11], gl[11]; // this branch's lattice states
-#pragma unroll
-    for (int i = 0; i < 11; i++) { gh[i] = hpf_g[i]; gl[i] = lpf_g[i]; }
-    float dx = s.dc_x[q], dy = s.dc_y[q];
-    const uint32_t half_off = ((q ^ (swap ? 1u : 0u)) & 1u) * 16u; // the half of a packed word this branch filters
+    // state that every lane carries along identically
     float nc[5], nd[2] = { s.notch_d[0], s.notch_d[1] };
 #pragma unroll
     for (int i = 0; i < 5; i++) nc[i] = s.notch_c[i];
@@ -356,119 +566,198 @@ __global__ __launch_bounds__(64) void ddc_audio_rx(AudioState *__restrict__ stat
     float fm_lpf = s.fm_lpf_prev, fm_ha = s.fm_hpf_a, fm_hb = s.fm_hpf_b, fm_ip = s.fm_i_prev, fm_qp = s.fm_q_prev;
     float fm_avg = s.fm_sql_avg;
     uint32_t fm_cnt = s.fm_sql_count, squelched = s.squelched, blocks = s.blocks;
-    const float A1 = 0.99951171875f; // 1 - 2^-11
+    float agc_gain = s.agc_gain, agc_gain_old = s.agc_gain_old;
+    const float agc_up = s.agc_up, agc_down = s.agc_down;
+    const bool agc_on = p.agc && m != DDC_MODE_DIGI_L && m != DDC_MODE_DIGI_U;
+    // noise reduction: taps and past samples in lanes 0..15, the two halves of the reference ring in all lanes
+    const bool dnr = chain && p.dnr;
+    float lms_w = 0, lms_px = 0, lms_energy = 0, lms_x0 = 0, ref_a = 0, ref_b = 0;
+    uint32_t ref_old = 0, ref_new = 0;
+    if (dnr) {
+        lms_w = lane < 16 ? s.lms_w[lane] : 0.0f;
+        lms_px = lane < 15 ? s.lms_hist[lane] : 0.0f;
+        lms_energy = s.lms_energy; lms_x0 = s.lms_x0;
+        ref_a = s.lms_ref[lane]; ref_b = s.lms_ref[64 + lane];
+        ref_old = s.ref_old; ref_new = s.ref_new;
+    }
 
     for (uint32_t b0 = 0; b0 + kABlock <= n_frames; b0 += kABlock) {
-        float first_angle = 0;
-        for (int i0 = 0; i0 < kABlock; i0 += 16) { // 16 samples per trip: the loads and stores go in 16-byte pieces
-            uint4 in4[4];
+        float fi[3], fq[3];
 #pragma unroll
-            for (int k = 0; k < 4; k++) in4[k] = reinterpret_cast<const uint4 *>(src + b0 + i0)[k];
-            const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
-                                      in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
-            int32_t out[32];
+        for (int j = 0; j < 3; j++) {
+            const float2 v = src[b0 + lane + 64 * j];
+            fi[j] = v.x;
+            fq[j] = v.y;
+        }
+        if (chain) {
+            if (ssb_l) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                float f = (float)(int)__builtin_amdgcn_sbfe(in[k], half_off, 16u);
-                { const float d = f - dx; const float a = A1 * dy; const float o = d + a; dx = f; dy = o; f = o * rf_gain; }
-                if (chain) {
-                    if (hpf) f = lattice_reg<6>(gh, hk, hv, f);
-                    if (lpf) {
-                        if (lpf_n == 11) f = lattice_reg<11>(gl, lk, lv, f);
-                        else f = lattice_reg<7>(gl, lk, lv, f);
-                    }
+                for (int j = 0; j < 3; j++) fi[j] = fi[j] - fq[j];
+            } else if (ssb_u) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) fi[j] = fi[j] + fq[j];
+            } else if (am) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float pw = fi[j] * fi[j] + fq[j] * fq[j];
+                    fi[j] = pw >= 0.0f ? sqrtf(pw) : 0.0f;
                 }
-                // the other branch's sample, from the neighbouring lane (quad_perm 1,0,3,2)
-                const float fo = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xF, 0xF, true));
-                float fi = q ? fo : f, fq = q ? f : fo;
-                if (chain) {
-                    if (ssb_l) fi = fi - fq;
-                    else if (ssb_u) fi = fi + fq;
-                    else if (am) {
-                        const float pw = fi * fi + fq * fq;
-                        fi = pw >= 0.0f ? sqrtf(pw) : 0.0f;
-                    } else { // DemodulateFM, audio_processor.c:509-559
-                        const float y = (fq * fm_ip) - (fi * fm_qp);
-                        const float x = (fi * fm_ip) + (fq * fm_qp);
-                        const float angle = atan2f(y, x);
-                        if (i0 + k == 0) first_angle = angle;
-                        const float a = fm_lpf + (0.05f * (angle - fm_lpf));
-                        fm_lpf = a;
-                        fm_qp = fq;
-                        fm_ip = fi;
-                        if (!squelched || !p.fm_sql_threshold) {
-                            if (m == DDC_MODE_WFM)
-                                fi = angle / kPiF * 16384.0f;
-                            else {
-                                const float bb = 0.96f * (fm_hb + a - fm_ha);
-                                fm_ha = a;
-                                fm_hb = bb;
-                                fi = bb * 30000.0f;
-                            }
-                        } else
-                            fi = 0;
-                    }
-                    if (notch) fi = biquad_step(nc, nd, fi);
+            } else { // DemodulateFM, audio_processor.c:509-559: the angle against the sample before, then the recursions
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 3; j++) { bi[lane + 64 * j] = fi[j]; bq[lane + 64 * j] = fq[j]; }
+                __syncthreads();
+                float ang[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t e = lane + 64 * j;
+                    const float ip = e ? bi[e - 1] : fm_ip, qp = e ? bq[e - 1] : fm_qp;
+                    const float y = (fq[j] * ip) - (fi[j] * qp);
+                    const float x = (fi[j] * ip) + (fq[j] * qp);
+                    ang[j] = atan2f(y, x);
                 }
-                if (fi > sm_max) sm_max = fi;
-                if (fq > sm_max) sm_max = fq;
-                if (fi < sm_min) sm_min = fi;
-                if (fq < sm_min) sm_min = fq;
-                if (chain) { if (owner) bi[i0 + k] = fi; }
-                else { out[2 * k] = f2i_sat(fi * vol); out[2 * k + 1] = f2i_sat(fq * vol); }
+                fm_ip = bi[kABlock - 1];
+                fm_qp = bq[kABlock - 1];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 3; j++) bi[lane + 64 * j] = ang[j];
+                __syncthreads();
+                const bool open = !squelched || !p.fm_sql_threshold;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                for (int ii = 0; ii < 64; ii++) {
+                    const float angle = bi[64 * j + ii];
+                    const float a = fm_lpf + (0.05f * (angle - fm_lpf));
+                    fm_lpf = a;
+                    float o = 0;
+                    if (open) {
+                        if (m == DDC_MODE_WFM)
+                            o = angle / kPiF * 16384.0f;
+                        else {
+                            const float bb = 0.96f * (fm_hb + a - fm_ha);
+                            fm_ha = a;
+                            fm_hb = bb;
+                            o = bb * 30000.0f;
+                        }
+                    }
+                    if ((uint32_t)ii == lane) fi[j] = o;
+                }
+                const float first_angle = bi[0];
+                // squelch, audio_processor.c:560-588
+                fm_avg = ((1.0f - 0.005f) * fm_avg) + (0.005f * sqrtf(fabsf(first_angle)));
+                if (fm_cnt == 0) {
+                    if (fm_avg > 0.7f) fm_avg = 0.7f;
+                    const float bsq = fm_avg * 10.0f;
+                    const int thr = p.fm_sql_threshold;
+                    if (!thr) squelched = 0;
+                    else if (squelched) {
+                        if (bsq <= (float)((10 - thr) - 0.3f)) squelched = 0;
+                    } else {
+                        if ((10.0f - thr) > 0.3f) {
+                            if (bsq > (float)((10 - thr) + 0.3f)) squelched = 1;
+                        } else if (bsq > (10.0f - (float)thr)) squelched = 1;
+                    }
+                    fm_cnt++; // only ever bumped here, as in the firmware
+                    if (fm_cnt >= 50) fm_cnt = 0;
+                }
             }
-            if (!chain && owner) {
+            if (notch) {
+                __syncthreads();
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    reinterpret_cast<int4 *>(dst + 2 * (b0 + i0))[k] = make_int4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+                for (int j = 0; j < 3; j++) bi[lane + 64 * j] = fi[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                for (int ii = 0; ii < 64; ii++) {
+                    const float o = biquad_step(nc, nd, bi[64 * j + ii]);
+                    if ((uint32_t)ii == lane) fi[j] = o;
+                }
             }
         }
-        if (fm) { // squelch, audio_processor.c:560-588
-            fm_avg = ((1.0f - 0.005f) * fm_avg) + (0.005f * sqrtf(fabsf(first_angle)));
-            if (fm_cnt == 0) {
-                if (fm_avg > 0.7f) fm_avg = 0.7f;
-                const float bsq = fm_avg * 10.0f;
-                const int thr = p.fm_sql_threshold;
-                if (!thr) squelched = 0;
-                else if (squelched) {
-                    if (bsq <= (float)((10 - thr) - 0.3f)) squelched = 0;
-                } else {
-                    if ((10.0f - thr) > 0.3f) {
-                        if (bsq > (float)((10 - thr) + 0.3f)) squelched = 1;
-                    } else if (bsq > (10.0f - (float)thr)) squelched = 1;
-                }
-                fm_cnt++; // only ever bumped here, as in the firmware
-                if (fm_cnt >= 50) fm_cnt = 0;
+        {   // S-meter extremes over both outputs of every frame
+            float hi = fmaxf(fmaxf(fi[0], fi[1]), fi[2]), lo = fminf(fminf(fi[0], fi[1]), fi[2]);
+            hi = fmaxf(hi, fmaxf(fmaxf(fq[0], fq[1]), fq[2]));
+            lo = fminf(lo, fminf(fminf(fq[0], fq[1]), fq[2]));
+            hi = wave_max(hi);
+            lo = wave_min(lo);
+            if (hi > sm_max) sm_max = hi;
+            if (lo < sm_min) sm_min = lo;
+        }
+        if (!chain) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) dst[b0 + lane + 64 * j] = make_int2(f2i_sat(fi[j] * vol), f2i_sat(fq[j] * vol));
+            blocks++;
+            continue;
+        }
+        if (dnr) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { // processNoiseReduction on each third of the block: the reference is the sub-block before
+                if (ref_new) ref_b = fi[j]; else ref_a = fi[j];
+                fi[j] = lms_lanes(fi[j], ref_old ? ref_b : ref_a, lms_w, lms_px, lms_energy, lms_x0, lane);
+                ref_old += kASub;
+                if (ref_old >= 128) ref_old = 0;
+                ref_new = ref_old + kASub;
+                if (ref_new >= 128) ref_new = 0;
             }
         }
-        if (chain && owner) {
-            if (p.dnr)
-                for (int sb = 0; sb < kABlock / kASub; sb++) {
-                    float *x = bi + sb * kASub;
-                    for (int i = 0; i < kASub; i++) s.lms_ref[s.ref_new + i] = x[i];
-                    lms_block(s, x);
-                    s.ref_old += kASub;
-                    if (s.ref_old >= 128) s.ref_old = 0;
-                    s.ref_new = s.ref_old + kASub;
-                    if (s.ref_new >= 128) s.ref_new = 0;
+        {   // DoAGC, agc.c:21-67
+            float mx = wave_max(fmaxf(fmaxf(fi[0], fi[1]), fi[2]));
+            if (mx == 0.0f) mx = 0.001f;
+            const float target = 7000 / mx;
+            if (target > agc_gain) {
+                float step = (target - agc_gain) / agc_up;
+                if (step > 1.0f) step = 1.0f;
+                agc_gain += step;
+            } else
+                agc_gain -= (agc_gain - target) / agc_down;
+            if (agc_gain < 0.0f) agc_gain = 0.0f;
+            if ((agc_gain * mx) > 10000) agc_gain = target;
+            if (!agc_on) agc_gain = 1.0f;
+            if (agc_gain_old != agc_gain) {
+                float step = 0;
+                if (agc_gain_old > agc_gain) step = -(agc_gain_old - agc_gain) / kABlock;
+                if (agc_gain_old < agc_gain) step = (agc_gain - agc_gain_old) / kABlock;
+                float g[3] = {0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                for (int ii = 0; ii < 64; ii++) { // the running gain is a sum of 192 steps, one after the other
+                    agc_gain_old += step;
+                    if ((uint32_t)ii == lane) g[j] = agc_gain_old;
                 }
-            agc_block(s, bi);
-            if (p.cw_decoder && (m == DDC_MODE_CW_L || m == DDC_MODE_CW_U)) cw_block(s, bi, 4ll * (int64_t)blocks);
-            for (int i0 = 0; i0 < kABlock; i0 += 2) { // doRX_COPYCHANNEL + volume: left = right
-                const int32_t a = f2i_sat(bi[i0] * vol), b = f2i_sat(bi[i0 + 1] * vol);
-                *reinterpret_cast<int4 *>(dst + 2 * (b0 + i0)) = make_int4(a, a, b, b);
+#pragma unroll
+                for (int j = 0; j < 3; j++) fi[j] = fi[j] * g[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; j++) fi[j] = fi[j] * agc_gain;
             }
+        }
+        if (p.cw_decoder && (m == DDC_MODE_CW_L || m == DDC_MODE_CW_U)) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 3; j++) bi[lane + 64 * j] = fi[j];
+            __syncthreads();
+            if (lane == 0) cw_block(s, bi, 4ll * (int64_t)blocks);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) { // doRX_COPYCHANNEL + volume: left = right
+            const int32_t a = f2i_sat(fi[j] * vol);
+            dst[b0 + lane + 64 * j] = make_int2(a, a);
         }
         blocks++;
     }
-#pragma unroll
-    for (int i = 0; i < 11; i++) { hpf_g[i] = gh[i]; lpf_g[i] = gl[i]; }
-    s.dc_x[q] = dx; s.dc_y[q] = dy;
-    if (!owner) return; // what follows is identical in both lanes
+    if (dnr) {
+        if (lane < 16) s.lms_w[lane] = lms_w;
+        if (lane < 15) s.lms_hist[lane] = lms_px;
+        s.lms_ref[lane] = ref_a;
+        s.lms_ref[64 + lane] = ref_b;
+        if (lane == 0) { s.lms_energy = lms_energy; s.lms_x0 = lms_x0; s.ref_old = ref_old; s.ref_new = ref_new; }
+    }
+    if (lane) return;
     s.notch_d[0] = nd[0]; s.notch_d[1] = nd[1];
     s.smeter_max = sm_max; s.smeter_min = sm_min;
     s.fm_lpf_prev = fm_lpf; s.fm_hpf_a = fm_ha; s.fm_hpf_b = fm_hb; s.fm_i_prev = fm_ip; s.fm_q_prev = fm_qp;
     s.fm_sql_avg = fm_avg; s.fm_sql_count = fm_cnt; s.squelched = squelched; s.blocks = blocks;
+    s.agc_gain = agc_gain; s.agc_gain_old = agc_gain_old;
 }
 
 /* ---- FFT panadapter ---------------------------------------------------------- */

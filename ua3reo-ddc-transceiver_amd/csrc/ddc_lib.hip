@@ -64,6 +64,8 @@ struct ddc_ctx {
     ddc_tx_state tx;
     // 48 kHz audio path / panadapter: per-channel state and FFT work buffers
     ddc::AudioState *d_audio = nullptr;
+    float2 *d_audio_filt = nullptr;    // [ch][frames] {I, Q} behind the RX audio filters
+    size_t audio_filt_cap = 0;         // frames per channel it holds
     ddc::ZoomState *d_zoom = nullptr;
     ddc::TxAudioState *d_audio_tx = nullptr;
     float *d_tx_xs = nullptr;          // [ch][200 + frames] gain-scaled TX audio ahead of the Hilbert FIR pair
@@ -573,7 +575,7 @@ void ddc_destroy(ddc_ctx *ctx)
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
                      ctx->d_out, ctx->d_tx_xs, ctx->d_fft_rows, ctx->d_wtf, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
-                     ctx->d_stage[2], ctx->d_cicf, ctx->d_edge, ctx->d_cnt, ctx->d_comp_tail };
+                     ctx->d_stage[2], ctx->d_cicf, ctx->d_edge, ctx->d_cnt, ctx->d_comp_tail, ctx->d_audio_filt };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     ddc_tx_state_destroy(&ctx->tx);
@@ -1373,8 +1375,17 @@ int ddc_audio_rx_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, const int16_t
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const uint32_t nch = ctx->cfg.n_channels;
-    hipLaunchKernelGGL(ddc::ddc_audio_rx, dim3((2 * nch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_audio, nch, spec_iq,
-                       voice_iq, (uint32_t)n_frames, audio_lr);
+    if (n_frames > ctx->audio_filt_cap) {
+        if (ctx->d_audio_filt) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_audio_filt); }
+        ctx->d_audio_filt = nullptr; ctx->audio_filt_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_audio_filt, (size_t)nch * n_frames * sizeof(float2)));
+        ctx->audio_filt_cap = n_frames;
+    }
+    // filters as a systolic pipeline (20 lanes per channel), then demodulator and block-wise stages (lane per channel)
+    hipLaunchKernelGGL(ddc::ddc_audio_rx_filters, dim3((nch + ddc::kFiltPerWave - 1) / ddc::kFiltPerWave), dim3(64), 0,
+                       ctx->stream, ctx->d_audio, nch, spec_iq, voice_iq, (uint32_t)n_frames, ctx->d_audio_filt);
+    hipLaunchKernelGGL(ddc::ddc_audio_rx_demod, dim3(nch), dim3(64), 0, ctx->stream, ctx->d_audio, nch,
+                       ctx->d_audio_filt, (uint32_t)n_frames, audio_lr);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
