@@ -118,3 +118,81 @@ def test_many_channels_two_tiles_each_three_calls(ddc, orc):
         assert np.array_equal(np.concatenate([o[1, i] for _, o in keep]), wv), c
     a.close()
     b.close()
+
+
+def test_shared_stream_status_registers_and_graph_replay_on_the_two_kernel_plan(ddc, orc):
+    """The corners of the two-kernel plan: one ADC row fanned out to every channel (row pitch 0),
+    the ADC min / max pass riding along, and a call of this shape captured once in a HIP graph on
+    the entry point that allocates nothing and replayed over fresh input."""
+    torch = pytest.importorskip("torch")
+    n_ch, n = 5, 2 * BLK
+    rng = np.random.default_rng(404)
+    x = rng.integers(-1500, 1500, 3 * n).astype(np.int16)
+    x[77] = 2047
+    x[n + 5] = -2048
+    phis = rng.integers(0, 1 << 22, n_ch).astype(np.uint32)
+    d = ddc.Ddc(n_ch)
+    d.tune_many(phis)
+    d.adc_stats_enable(True)
+    outs = [d.rx_process(ddc.pack_adc12(x[k * n:(k + 1) * n])[None, :], n, row_bytes=0) for k in range(2)]
+    spec = np.concatenate([o[0] for o in outs], axis=1)
+    voice = np.concatenate([o[1] for o in outs], axis=1)
+    for c in range(n_ch):
+        ws, wv = orc.RxChain(int(phis[c])).run(x[:2 * n])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+    otr, _, lo, hi = ddc.parse_status(d.get_status(0))
+    assert (lo, hi, otr) == (-2048, 2047 & 0xFFF, 1)
+    d.close()
+    # graph replay: three chunks through one captured static call
+    rb = n // 2 * 3
+    e = ddc.Ddc(n_ch)
+    e.tune_many(phis)
+    side = torch.cuda.Stream()
+    e.set_stream(side.cuda_stream)
+    adc = torch.zeros((rb,), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((2, n_ch, n // 1024, 2), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+        e.rx_process_dev_static(adc.data_ptr(), 0, n, out[0].data_ptr(), out[1].data_ptr())
+    got = []
+    for k in range(3):
+        adc.copy_(torch.from_numpy(ddc.pack_adc12(x[k * n:(k + 1) * n])))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got.append(out.cpu().numpy().copy())
+    for c in (0, n_ch - 1):
+        ws, wv = orc.RxChain(int(phis[c])).run(x)
+        assert np.array_equal(np.concatenate([o[0, c] for o in got]), ws), c
+        assert np.array_equal(np.concatenate([o[1, c] for o in got]), wv), c
+    e.set_stream(None)
+    e.close()
+
+
+def test_state_blob_travels_between_the_two_plans(ddc, orc):
+    """A state blob saved after a two-kernel call restores into a ctx that goes on with the
+    six-kernel plan (and the other way round): the carried state has one format."""
+    n_ch = 2
+    rng = np.random.default_rng(505)
+    x = rng.integers(-2048, 2048, size=(n_ch, 3 * BLK)).astype(np.int16)
+    phis = [605867, 31337]
+    a = ddc.Ddc(n_ch)
+    a.tune_many(phis)
+    a.rx_process(np.stack([ddc.pack_adc12(r[:BLK]) for r in x]), BLK)           # two kernels
+    blob = a.state_save()
+    b = ddc.Ddc(n_ch)
+    b.state_restore(blob)
+    b.debug_rx_plan(1)
+    s1, v1 = b.rx_process(np.stack([ddc.pack_adc12(r[BLK:2 * BLK]) for r in x]), BLK)  # six kernels
+    blob2 = b.state_save()
+    c = ddc.Ddc(n_ch)
+    c.state_restore(blob2)
+    s2, v2 = c.rx_process(np.stack([ddc.pack_adc12(r[2 * BLK:]) for r in x]), BLK)      # two kernels again
+    for ch in range(n_ch):
+        ws, wv = orc.RxChain(phis[ch]).run(x[ch])
+        nf = BLK // 1024
+        assert np.array_equal(s1[ch], ws[nf:2 * nf]) and np.array_equal(v1[ch], wv[nf:2 * nf])
+        assert np.array_equal(s2[ch], ws[2 * nf:]) and np.array_equal(v2[ch], wv[2 * nf:])
+    for d_ in (a, b, c):
+        d_.close()

@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/ua3reo_ddc.h"
 #include "ddc_audio_coeffs.h"
@@ -811,7 +812,10 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
     for (int r = 0; r < kRing; r++)
 #pragma unroll
         for (int k = 0; k < 4; k++) ring[r][k] = reinterpret_cast<const uint4 *>(src + 16 * r)[k];
-    auto trip = [&](const uint4 (&in4)[4], const uint32_t i0) {
+    // the notch is a per-channel setting: when no lane of the wave has it on (the usual case) the
+    // sample loop runs without the biquad and without a branch around it
+    const bool any_notch = __any(notch);
+    auto trip = [&](const uint4 (&in4)[4], const uint32_t i0, auto with_notch) {
         const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
                                   in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
         float out[16];
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
         for (int k = 0; k < 16; k++) {
             float f = (float)(int)__builtin_amdgcn_sbfe(in[k], half_off, 16u); // the builtin is typed unsigned
             { const float d = f - dx; const float a = A1 * dy; const float o = d + a; dx = f; dy = o; f = o; }
-            if (notch) f = biquad_step(c, nd, f);
+            if (decltype(with_notch)::value) { if (notch) f = biquad_step(c, nd, f); }
             if (M == 1) { out[k] = f; continue; }
 #pragma unroll
             for (int sg = 0; sg < 4; sg++) { // arm_biquad_cascade_df1_f32: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2
@@ -853,7 +857,8 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
 #pragma unroll
                 for (int k = 0; k < 4; k++) ring[r][k] = reinterpret_cast<const uint4 *>(src + ahead)[k];
             }
-            trip(cur, i0 + 16 * r);
+            if (any_notch) trip(cur, i0 + 16 * r, std::true_type{});
+            else trip(cur, i0 + 16 * r, std::false_type{});
         }
     }
     s.dc_x[4 + q] = dx; s.dc_y[4 + q] = dy;
