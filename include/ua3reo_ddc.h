@@ -204,7 +204,10 @@ void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_i
  * flag as the FPGA uses it (clock enable of one direction, reset of the other): when
  * the flag differs from the channel's last one, the direction that is switched on is
  * reset to zero state (ddc_tx_reset / ddc_rx_reset).  A ctx starts in RX.  The preamp
- * bit belongs to the RF unit and is ignored. */
+ * bit belongs to the RF unit and is ignored.  The flag gates nothing else: a
+ * ddc_rx_process* or ddc_tx_process* call runs whatever the channel's flag says (in the
+ * FPGA the idle direction has no clock), and ddc_tune / ddc_rx_reset / ddc_tx_reset do
+ * not touch the flag; a host that mixes directions per channel skips the calls itself. */
 int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4]);
 
 /* Status frame: command 2 reply of the bus (FPGA/stm32_interface.v:172-205), read

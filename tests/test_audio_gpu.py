@@ -369,13 +369,13 @@ def test_usb_audio_frames_match_oracle(ddc, orc):
 
 
 def test_config3_chain_256_channels_ddc_into_panadapter(ddc, orc):
-    """BASELINE config 3 at its shape: 256 tuned channels x 2^20 ADC samples through
-    ddc_rx_process_dev -> ddc_fft_process_dev on device buffers (two panadapter rows per
+    """BASELINE config 3 at its shape: 256 tuned channels x 2^22 ADC samples through
+    ddc_rx_process_dev -> ddc_fft_process_dev on device buffers (eight panadapter rows per
     channel).  One call equals two half calls for every channel, bit for bit, and
     channels 0, 127 and 255 match the oracle chain (SPEC exactly, bins within 1e-4 of the
     frame maximum, colour rows up to boundary pixels)."""
     torch = pytest.importorskip("torch")
-    n_ch, samples = 256, 1 << 20
+    n_ch, samples = 256, 1 << 22
     rb = samples // 2 * 3
     nf = samples // 1024
     probe = (0, 127, 255)
@@ -426,7 +426,7 @@ def test_config3_chain_256_channels_ddc_into_panadapter(ddc, orc):
             wb, wr, _ = a.fft(ws[512 * f:512 * (f + 1)])
             assert np.abs(b1[c, f] - wb).max() <= 1e-4 * max(float(wb.max()), 1e-3), (c, f)
             bad_pixels += int((r1[c, f] != wr).sum())
-    assert bad_pixels <= 4
+    assert bad_pixels <= 12   # of 3 channels x 8 rows x 256 pixels: bins that sit on a colour boundary
 
 
 def test_config2_one_channel_one_second_to_audio(ddc, orc):

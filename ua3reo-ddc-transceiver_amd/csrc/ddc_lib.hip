@@ -118,6 +118,11 @@ int fail(ddc_ctx *ctx, int code, const std::string &msg)
 
 long rnd_half_away(double x) { return (long)(x >= 0 ? std::floor(x + 0.5) : -std::floor(-x + 0.5)); }
 
+// {fine sine, 8191} as 16-bit halves for fine phase f, in integers: what the kernels' float multiply-add on a
+// denormal (ddc::nco_fine_pair) must produce.  The host never evaluates the float form: a host thread that
+// flushes denormals would get it wrong while the GPU is fine.
+uint32_t nco_fine_pair_host(uint32_t f) { return (8191u << 16) | (uint32_t)((f * DDC_SF_K + DDC_SF_R) >> 24); }
+
 // Coarse NCO table for the kernels and a check that the arithmetic fine-sine
 // shortcut reproduces the 2048-entry fine ROM.
 int build_nco_table(std::vector<uint2> &tab)
@@ -134,7 +139,7 @@ int build_nco_table(std::vector<uint2> &tab)
         const long sf = rnd_half_away(8191.0 * std::sin(two_pi * fi / 4194304.0));
         const long cf = rnd_half_away(8191.0 * std::cos(two_pi * fi / 4194304.0));
         if ((long)((fi * DDC_SF_K + DDC_SF_R) >> 24) != sf || cf != 8191) return -1;
-        if (ddc::nco_fine_pair(fi) != ((8191u << 16) | (uint32_t)sf)) return -1;
+        if (nco_fine_pair_host(fi) != ((8191u << 16) | (uint32_t)sf)) return -1;
     }
     return 0;
 }
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void ddc_nco_sweep(const uint2 *__restrict__ n
         int s, c;
         nco14x(tab2, acc30, s, c);
         out[i] = (int16_t)(s >> 16);
-        out[count + i] = (int16_t)(c >> 16);
+        out[(size_t)count + i] = (int16_t)(c >> 16);
         // RX: the mixer multiplies the ADC sample by these two and returns the products
         int pi, pq;
         nco_mix(tab, acc30, 1, pi, pq);
@@ -484,7 +489,7 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         CREATE_TRY(hipMemcpyAsync(got.data(), ctx->d_nco_tab, 2048 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CREATE_TRY(hipStreamSynchronize(ctx->stream));
         for (uint32_t f = 0; f < 2048; f++)
-            if (got[f] != ddc::nco_fine_pair(f)) {
+            if (got[f] != nco_fine_pair_host(f)) {
                 ctx->err = "this device evaluates the NCO fine sine differently from the host (denormals flushed?)";
                 return bail(-EFAULT);
             }
@@ -643,13 +648,20 @@ int ddc_tune_hz(ddc_ctx *ctx, int32_t channel, uint32_t freq_hz, int *iq_swap)
     return ddc_tune(ctx, channel, ddc_phrase_from_frequency(freq_hz, ctx->cfg.fs_adc, iq_swap) & 0x3FFFFF);
 }
 
+static int rx_reset_range(ddc_ctx *ctx, size_t lo, size_t n, bool all);
+
 int ddc_rx_reset(ddc_ctx *ctx, int32_t channel)
 {
     int rc = check_channel(ctx, channel);
     if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const size_t lo = channel < 0 ? 0 : (size_t)channel;
     const size_t n = channel < 0 ? ctx->cfg.n_channels : 1;
+    return rx_reset_range(ctx, lo, n, channel < 0);
+}
+
+static int rx_reset_range(ddc_ctx *ctx, size_t lo, size_t n, bool all)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc + lo, 0, n * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_carry[0] + lo * 6, 0, n * 24, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_carry[1] + lo * 6, 0, n * 24, ctx->stream));
@@ -657,7 +669,7 @@ int ddc_rx_reset(ddc_ctx *ctx, int32_t channel)
                                 n * ddc::kMomHist * 10 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_cic + lo * ddc::kCicHist * 2, 0, n * ddc::kCicHist * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist_comp + lo * ddc::kCompHist * 2, 0, n * ddc::kCompHist * 4, ctx->stream));
-    if (channel < 0 && ctx->d_cnt) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cnt, 0, (ctx->cnt_words + 3) / 4 * 16, ctx->stream));
+    if (all && ctx->d_cnt) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cnt, 0, (ctx->cnt_words + 3) / 4 * 16, ctx->stream));
     return 0;
 }
 
@@ -1083,13 +1095,20 @@ int ddc_allgather_wait(ddc_ctx *ctx, int slot, float *gather_ms)
 
 /* ---- TX ---------------------------------------------------------------- */
 
+static int tx_reset_range(ddc_ctx *ctx, size_t lo, size_t n);
+
 int ddc_tx_reset(ddc_ctx *ctx, int32_t channel)
 {
     int rc = check_channel(ctx, channel);
     if (rc) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     const size_t lo = channel < 0 ? 0 : (size_t)channel;
     const size_t n = channel < 0 ? ctx->cfg.n_channels : 1;
+    return tx_reset_range(ctx, lo, n);
+}
+
+static int tx_reset_range(ddc_ctx *ctx, size_t lo, size_t n)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->tx.d_acc + lo, 0, n * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->tx.d_hist_x + lo * ddc::kTxXHist * 2, 0, n * ddc::kTxXHist * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->tx.d_hist_y + lo * ddc::kTxYHist * 2, 0, n * ddc::kTxYHist * 4, ctx->stream));
@@ -1893,6 +1912,11 @@ void ddc_parse_params(const uint8_t in[4], int *tx, int *preamp, uint32_t *phi_i
     if (phi_inc22) *phi_inc22 = ((uint32_t)(in[1] & 0x3F) << 16) | ((uint32_t)in[2] << 8) | in[3];
 }
 
+static int reset_range(ddc_ctx *ctx, bool tx, uint32_t lo, uint32_t n)
+{
+    return tx ? tx_reset_range(ctx, lo, n) : rx_reset_range(ctx, lo, n, n == ctx->cfg.n_channels);
+}
+
 int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
 {
     int tx = 0, pre = 0;
@@ -1905,11 +1929,16 @@ int ddc_set_params(ddc_ctx *ctx, int32_t channel, const uint8_t in[4])
     // the other, so the direction that is switched on starts from zero state
     const uint32_t lo = channel < 0 ? 0 : (uint32_t)channel;
     const uint32_t hi = channel < 0 ? ctx->cfg.n_channels : (uint32_t)channel + 1;
-    for (uint32_t c = lo; c < hi; c++) {
-        if ((ctx->tx_dir[c] != 0) == (tx != 0)) continue;
-        rc = tx ? ddc_tx_reset(ctx, (int32_t)c) : ddc_rx_reset(ctx, (int32_t)c);
+    // channels whose flag flips, reset run by run (one set of memsets per run of neighbours)
+    uint32_t c = lo;
+    while (c < hi) {
+        if ((ctx->tx_dir[c] != 0) == (tx != 0)) { c++; continue; }
+        uint32_t e = c;
+        while (e < hi && (ctx->tx_dir[e] != 0) != (tx != 0)) e++;
+        rc = reset_range(ctx, tx != 0, c, e - c);
         if (rc) return rc;
-        ctx->tx_dir[c] = tx ? 1 : 0;
+        for (uint32_t k = c; k < e; k++) ctx->tx_dir[k] = tx ? 1 : 0;
+        c = e;
     }
     return ddc_tune(ctx, channel, phi);
 }
@@ -1922,6 +1951,7 @@ int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *s
     if (!ctx) return -EINVAL;
     if (count == 0) return 0;
     if (!sin14 || !cos14) return fail(ctx, -EINVAL, "null buffer");
+    if (count > (1u << 22)) return fail(ctx, -EINVAL, "ddc_debug_nco: at most 2^22 phases (one turn of the accumulator) per call");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     int16_t *d = nullptr;
     HIP_TRY(ctx, hipMalloc(&d, (size_t)count * 4 * sizeof(int16_t)));
@@ -1973,7 +2003,7 @@ int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
         n = nco.size() * sizeof(uint2);
     } else if (k == "nco_fine_sine") { // the kernels' arithmetic fine sine for every 11-bit fine phase
         fine.resize(2048);
-        for (uint32_t f = 0; f < 2048; f++) fine[f] = (int16_t)(ddc::nco_fine_pair(f) & 0xFFFFu);
+        for (uint32_t f = 0; f < 2048; f++) fine[f] = (int16_t)(nco_fine_pair_host(f) & 0xFFFFu);
         src = fine.data();
         n = fine.size() * sizeof(int16_t);
     }
@@ -2035,8 +2065,9 @@ int ddc_synth_adc_dev(uint32_t first_channel, uint32_t n_channels, uint32_t fs_a
     if (!rows || n_channels == 0) return fail(nullptr, -EINVAL, "null buffer");
     if (samples == 0 || samples % ddc::kSynthSeg) return fail(nullptr, -EINVAL, "samples must be a multiple of 512");
     if (row_bytes < samples / 2 * 3) return fail(nullptr, -EINVAL, "row_bytes smaller than one row of samples");
-    if (samples / ddc::kSynthSeg > 0xFFFFFFFFull || (unsigned long long)n_channels * (samples / ddc::kSynthSeg) >= (1ull << 40))
-        return fail(nullptr, -EINVAL, "too many samples");
+    // one thread per 512-sample segment, 256 per workgroup, and the workgroup count is a 32-bit number
+    if (samples / ddc::kSynthSeg > 0xFFFFFFFFull || (unsigned long long)n_channels * (samples / ddc::kSynthSeg) >= (1ull << 39))
+        return fail(nullptr, -EINVAL, "too many samples (at most 2^39 segments of 512 samples per call)");
     if (fs_adc == 0) fs_adc = DDC_ADC_CLOCK_DEFAULT;
     hipStream_t st = (hipStream_t)hip_stream;
     const uint32_t n_seg = (uint32_t)(samples / ddc::kSynthSeg);
