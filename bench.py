@@ -360,7 +360,7 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     check = "skipped"
     if not args.no_check:
         from oracle import oracle
-        ns = min(S, 1 << 19) if with_fft else min(S, 1 << 16)
+        ns = min(S, 1 << 19) if with_fft else min(S, 1 << 17)  # 2^17 samples: the same call plan as the timed shape
         chk_ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
         chk_ctx.tune_many(phis)
         chk_out = torch.zeros((2, nch, ns // 1024, 2), dtype=torch.int16, device=dev)

@@ -6,7 +6,7 @@ tag=${1:-ab}; shift
 out=gpurun_out/$tag; mkdir -p $out
 for rep in 1 2 3; do
   for plan in auto split; do
-    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-copy-rate --steps 40 --rx-plan $plan "$@" > $out/${plan}_$rep.json 2> $out/${plan}_$rep.err || { echo "$plan failed"; tail -5 $out/${plan}_$rep.err; exit 1; }
+    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-copy-rate --no-secondary --steps 40 --rx-plan $plan "$@" > $out/${plan}_$rep.json 2> $out/${plan}_$rep.err || { echo "$plan failed"; tail -5 $out/${plan}_$rep.err; exit 1; }
     python3 -c "
 import json,sys;d=json.load(open('$out/${plan}_$rep.json'));print('$plan',$rep,'ms_per_step',d['ms_per_step'],'kernel',d['roofline']['avg_launch_ms'],'rest',d['roofline']['rest_of_call_ms'])"
   done

@@ -3,7 +3,7 @@
 tag=$1; shift
 mkdir -p gpurun_out/$tag
 for n in "$@"; do
-    UA3REO_DDC_LIB=$PWD/build/exp/lib_$n.so timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-copy-rate --steps 20 --warmup 3 $BENCH_EXTRA > gpurun_out/$tag/$n.json 2> gpurun_out/$tag/$n.err || { echo "$n FAILED"; tail -3 gpurun_out/$tag/$n.err; exit 1; }
+    UA3REO_DDC_LIB=$PWD/build/exp/lib_$n.so timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-copy-rate --no-secondary --steps 20 --warmup 3 $BENCH_EXTRA > gpurun_out/$tag/$n.json 2> gpurun_out/$tag/$n.err || { echo "$n FAILED"; tail -3 gpurun_out/$tag/$n.err; exit 1; }
     python3 - gpurun_out/$tag/$n.json $n <<'PY'
 import json, sys
 r = json.load(open(sys.argv[1]))

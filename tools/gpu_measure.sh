@@ -16,14 +16,14 @@ timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || { echo
 cat $out/bench.json
 
 step kernel-trace
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --no-cpu-baseline > $out/trace.log 2>&1 || { echo "trace failed"; tail -20 $out/trace.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --no-cpu-baseline --no-secondary > $out/trace.log 2>&1 || { echo "trace failed"; tail -20 $out/trace.log; exit 1; }
 find $out/trace -name "*kernel_stats.csv" | head -1 | xargs -r cat > $out/kernel_stats.csv
 head -20 $out/kernel_stats.csv
 
 step pmc-fetch
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-copy-rate > $out/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -20 $out/pmc_fetch.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-copy-rate --no-secondary > $out/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; tail -20 $out/pmc_fetch.log; exit 1; }
 step pmc-write
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-copy-rate > $out/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -20 $out/pmc_write.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-copy-rate --no-secondary > $out/pmc_write.log 2>&1 || { echo "pmc write failed"; tail -20 $out/pmc_write.log; exit 1; }
 python3 tools/pmc_summary.py $out/pmc_fetch > $out/pmc_summary.txt
 python3 tools/pmc_summary.py $out/pmc_write >> $out/pmc_summary.txt
 cat $out/pmc_summary.txt

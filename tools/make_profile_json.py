@@ -2,14 +2,16 @@
 """Turns the PMC summaries of one measurement round into the two small JSON files
 bench.py replays next to its live timing (it cannot read counters from inside a run):
 
-  profiles/traffic.json  HBM-side bytes per ddc_rx_front launch (2 x FETCH_SIZE + WRITE_SIZE,
+  profiles/traffic.json  HBM-side bytes per ddc_rx_front_cic launch (2 x FETCH_SIZE + WRITE_SIZE,
                          KiB -> bytes; gfx950 tallies 128-byte fills at 64 bytes)
   profiles/valu.json     vector instructions per ADC sample (SQ_INSTS_VALU), split into the two
                          issue classes the probe (tools/probe/valu_issue.hip) found, with the
                          probe's cycles per wave-instruction per SIMD and the clock of the pass
 
-Both carry the hash of the kernel source they were measured on and the commit; bench.py
-ignores them once csrc/ddc_rx_kernels.hip.h has changed.
+Both carry the hash of the kernel source they were measured on and the commit that holds it;
+bench.py ignores them once csrc/ddc_rx_kernels.hip.h has changed.  The tool refuses to write while
+the kernel sources in the tree differ from HEAD: a counter pass is only worth recording against a
+source that is in the history.
 
 usage: tools/make_profile_json.py --sq gpurun_out/<tag>/pmc_sq.txt --traffic gpurun_out/<tag>/pmc_summary.txt
            --clock-ghz 2.03 [--channels 1024 --samples 1048576] --source "<what was run>"
@@ -23,7 +25,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_rx_kernels.hip.h")
-KERNEL = "ddc::ddc_rx_front"
+KERNEL = "ddc::ddc_rx_front_cic"
 # issue classes (profiles/r02_valu_issue_probe.txt): ~2.1 cycles per wave-instruction per SIMD
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32", "v_or_b32",
         "v_xor_b32", "v_mov_b32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32", "v_mul_f32", "v_add_f32",
@@ -47,12 +49,12 @@ def medians(path, kernel):
 
 
 def static_mix():
-    """Fractions (slow, fast) of the vector instructions of ddc_rx_front, blocks of the sample loop
+    """Fractions (slow, fast) of the vector instructions of ddc_rx_front_cic, blocks of the sample loop
     weighted by its 16 trips, from the compiler's assembly of the source in the tree."""
     asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-",
                           os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_lib.hip")],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
-    i = asm.index("\n_ZN3ddc12ddc_rx_frontE")
+    i = asm.index("\n_ZN3ddc16ddc_rx_front_cicE")
     body = asm[i:asm.index("s_endpgm", i)].split("\n")
     # the sample loop is the loop with the most instructions
     loops, cur = {}, None
@@ -96,9 +98,14 @@ def main():
     ap.add_argument("--source", default="tools/pmc_sq.sh / tools/gpu_measure.sh")
     a = ap.parse_args()
     sha = hashlib.sha256(open(SRC, "rb").read()).hexdigest()[:16]
-    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE).stdout.decode().strip()
-    common = {"kernel": "ddc_rx_front", "channels": a.channels, "samples": a.samples, "kernel_source_sha256_16": sha,
-              "commit": commit + " (+ working tree)"}
+    git = lambda *args: subprocess.run(["git", "-C", ROOT] + list(args), stdout=subprocess.PIPE, check=True).stdout.decode().strip()
+    dirty = git("status", "--porcelain", "--", "ua3reo-ddc-transceiver_amd/csrc", "include", "bench.py")
+    if dirty:
+        raise SystemExit("make_profile_json: kernel sources / bench.py differ from HEAD, commit them first:\n" + dirty)
+    commit = git("rev-parse", "--short", "HEAD")
+    blob = git("rev-parse", "HEAD:ua3reo-ddc-transceiver_amd/csrc/ddc_rx_kernels.hip.h")
+    common = {"kernel": "ddc_rx_front_cic", "channels": a.channels, "samples": a.samples, "kernel_source_sha256_16": sha,
+              "commit": commit, "kernel_source_git_blob": blob}
     if a.traffic:
         m = medians(a.traffic, KERNEL)
         t = dict(common, source=a.source + " (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs)",

@@ -484,21 +484,31 @@ __device__ __forceinline__ void hilbert_quad_sums(const uint4 *src, const uint32
     }
 }
 
-// output o of the tile from its plain dot product S and the bit planes
-__device__ __forceinline__ int16_t hilbert_round(int S, uint32_t o, const uint32_t *p0, const uint32_t *p1)
+// The four outputs o0, o0 + 2, o0 + 4, o0 + 6 of a thread (o0 = 8 g + par) from their plain dot
+// products S and the bit planes: their 256-bit windows start in the same dword (o0 mod 32 is at most
+// 25), so nine dwords of each plane serve all four.
+__device__ __forceinline__ void hilbert_round4(const int (&S)[4], uint32_t o0, const uint32_t *p0, const uint32_t *p1,
+                                               int16_t (&y)[4])
 {
-    const uint32_t w0 = o >> 5, sh = o & 31u;
-    uint32_t n1 = 0, n3 = 0;
+    const uint32_t w0 = o0 >> 5, sh0 = o0 & 31u;
+    uint32_t a[9], b[9];
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-        const uint32_t a0 = __builtin_amdgcn_alignbit(p0[w0 + d + 1], p0[w0 + d], sh);
-        const uint32_t a1 = __builtin_amdgcn_alignbit(p1[w0 + d + 1], p1[w0 + d], sh);
-        const uint32_t both = a0 & c_hilb_odd[d];
-        n1 += __popc(both);
-        n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
+    for (int d = 0; d < 9; d++) { a[d] = p0[w0 + d]; b[d] = p1[w0 + d]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t sh = sh0 + 2u * k;
+        uint32_t n1 = 0, n3 = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const uint32_t a0 = __builtin_amdgcn_alignbit(a[d + 1], a[d], sh);
+            const uint32_t a1 = __builtin_amdgcn_alignbit(b[d + 1], b[d], sh);
+            const uint32_t both = a0 & c_hilb_odd[d];
+            n1 += __popc(both);
+            n3 += __popc((a1 ^ c_hilb_bit1[d]) & both);
+        }
+        const uint32_t acc = (((uint32_t)S[k] - n1) >> 1) + n3;
+        y[k] = (int16_t)cround32(acc, 14, 30);
     }
-    const uint32_t acc = (((uint32_t)S - n1) >> 1) + n3;
-    return (int16_t)cround32(acc, 14, 30);
 }
 
 // Bit planes of the staged samples sa[0 .. kHilbIn): all 256 threads, after the samples are in LDS.
@@ -732,13 +742,14 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
     hilbert_quad_sums(reinterpret_cast<const uint4 *>(xa) + par * (kHilbIn / 8) + g,
                       reinterpret_cast<const uint32_t *>(lds + kLdsTaps), S);
     uint32_t *voice32 = reinterpret_cast<uint32_t *>(fa.voice_iq) + (size_t)ch * nf;
+    int16_t vi[4];
+    hilbert_round4(S, 8 * g + par, p0, p1, vi);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
         if (n >= n1) continue;
-        const int16_t vi = hilbert_round(S[k], o, p0, p1);
         const int16_t vq = cq[o + 126]; // frame n - 130 (FPGA/data_delay.v, delay_length = 130)
-        voice32[n] = (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
+        voice32[n] = (uint32_t)(uint16_t)vi[k] | ((uint32_t)(uint16_t)vq << 16);
     }
 }
 
@@ -1245,14 +1256,15 @@ __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict_
     const uint32_t par = t >> 7, g = t & 127u;
     int S[4];
     hilbert_quad_sums(reinterpret_cast<const uint4 *>(&xs[0][0]) + par * (kHilbIn / 8) + g, taps, S);
+    int16_t vi[4];
+    hilbert_round4(S, 8 * g + par, p0, p1, vi);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
         if (n >= nf) continue;
-        const int16_t vi = hilbert_round(S[k], o, p0, p1);
         const int16_t vq = (int16_t)((int)x[kCompHist + n - 130] >> 16);
         reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
-            (uint32_t)(uint16_t)vi | ((uint32_t)(uint16_t)vq << 16);
+            (uint32_t)(uint16_t)vi[k] | ((uint32_t)(uint16_t)vq << 16);
     }
 }
 
