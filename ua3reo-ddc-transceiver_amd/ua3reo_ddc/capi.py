@@ -55,6 +55,9 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
+    if os.environ.get("UA3REO_DDC_LIB"):
+        import sys
+        sys.stderr.write("ua3reo_ddc: loading %s (UA3REO_DDC_LIB is set)\n" % _SO)
     L = C.CDLL(_SO)
     vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32
     L.ddc_create.argtypes = [vp, C.POINTER(vp)]
