@@ -76,6 +76,10 @@ def parse_args(argv=None):
                          "split: the separate kernels, for A/B timing on one box")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU)")
+    ap.add_argument("--gather", choices=["library", "torch"], default="library",
+                    help="library: ddc_allgather_decimated_dev (RCCL behind the C ABI; ranks fall back to torch together, "
+                         "and say so in the line, if its communicator cannot be built); torch: torch.distributed's "
+                         "all_gather_into_tensor with the same double buffering")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="no GPU: gloo ranks on CPUs, a pattern instead of the kernels; checks launch + gather + JSON")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself")
@@ -249,7 +253,7 @@ def main(argv=None):
     import numpy as np
     import torch
     do_gather = world > 1 or args.force_gather
-    if world > 1:
+    if world > 1 or (args.force_gather and args.gather == "torch"):
         import torch.distributed as dist
         # stdout carries the one JSON line: RCCL's own banner / debug text goes to stderr
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
@@ -329,31 +333,70 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     # overlaps the compute of step k+1 (ua3reo_ddc/shard.py, StepGather)
     outs = torch.zeros((2, 2, nch, nf, 2), dtype=torch.int16, device=dev)
     gathered = None
+    sg = None            # torch.distributed stand-in, only if the library's communicator cannot be built
+    gather_path = None
     if do_gather:
         # the library's own collective (ddc_allgather_decimated_dev: one ncclAllGather of bytes on a second
         # stream, two slots); the communicator id travels over torch.distributed, which the ranks have anyway
-        gathered = torch.zeros((2, world, 2, nch, nf, 2), dtype=torch.int16, device=dev)
-        if world > 1:
-            box = [ua3reo_ddc.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm_id = box[0]
-        else:
+
+        def all_ranks_ok(ok):
+            if world == 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        why = None
+        try:
+            if args.gather == "torch":
+                raise RuntimeError("--gather torch")
+            # every rank binds RCCL here, so that a rank without the library shows before anyone waits for it
             comm_id = ua3reo_ddc.comm_unique_id()
-        with _StdoutToStderr():
-            ctx.comm_init(world, rank, comm_id)
+        except Exception as e:  # noqa: BLE001 (reported in the JSON line)
+            why = "%s: %s" % (type(e).__name__, e)
+        if all_ranks_ok(why is None):
+            if world > 1:
+                box = [comm_id if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm_id = box[0]
+            try:
+                with _StdoutToStderr():
+                    ctx.comm_init(world, rank, comm_id)
+            except Exception as e:  # noqa: BLE001
+                why = "%s: %s" % (type(e).__name__, e)
+            if all_ranks_ok(why is None):
+                gather_path = "library"
+                gathered = torch.zeros((2, world, 2, nch, nf, 2), dtype=torch.int16, device=dev)
+            elif why is None:
+                ctx.comm_destroy()
+                why = "ddc_comm_init failed on another rank"
+        elif why is None:
+            why = "RCCL could not be bound on another rank"
+        if gather_path is None and dist is None:
+            raise SystemExit("bench: the library's communicator could not be built: %s" % why)
+        if gather_path is None:
+            sys.stderr.write("bench: rank %d gathers over torch.distributed (%s)\n" % (rank, why))
+            gather_path = "torch.distributed (the library's communicator could not be built: %s)" % why
+            sg = shard.StepGather(dist, (2, nch, nf, 2), torch.int16, dev, compute_stream=ext, timed=True)
+            outs, gathered = sg.outs, sg.gathered
     step_no = [0]
     torch.cuda.synchronize()
 
     def step():
         k = step_no[0]
         step_no[0] += 1
-        o = outs[k & 1]
-        if do_gather:
-            ctx.allgather_reuse(k & 1)  # the gather of step k - 2 has read this buffer
+        if sg:
+            o = sg.buffer(k)
+        else:
+            o = outs[k & 1]
+            if do_gather:
+                ctx.allgather_reuse(k & 1)  # the gather of step k - 2 has read this buffer
         ctx.rx_process_dev(adc.data_ptr(), pitch, S, o[0].data_ptr(), o[1].data_ptr())
         if with_fft:
             ctx.fft_process_dev(o[0].data_ptr(), nf, fft_bins.data_ptr(), fft_rows.data_ptr())
-        if do_gather:
+        if sg:
+            sg.submit(k)
+        elif do_gather:
             ctx.allgather_decimated_dev(k & 1, o.data_ptr(), nf, gathered[k & 1].data_ptr())
 
     # parity spot check before any timing: first call from power-on state vs the oracle
@@ -396,7 +439,11 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     for _ in range(args.warmup):
         step()
     ctx.sync()
-    if do_gather:
+    if sg:
+        sg.finish()
+        if sg.times is not None:
+            sg.times.clear()
+    elif do_gather:
         ctx.allgather_wait(-1)
     torch.cuda.synchronize()
     ctx.profile_enable(True)
@@ -408,7 +455,10 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
         step()
     ctx.sync()
     gather_ms = []
-    if do_gather:
+    if sg:
+        sg.finish()
+        gather_ms = [sg.average_ms()] if sg.times else []
+    elif do_gather:
         gather_ms = [ctx.allgather_wait(b) for b in range(min(2, args.steps))]
     torch.cuda.synchronize()
     if dist is not None:
@@ -530,11 +580,15 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
             g_ms = sum(gather_ms) / len(gather_ms)
             k_last = step_no[0] - 1
             ok = bool(torch.equal(gathered[k_last & 1][rank], outs[k_last & 1]))
-            res["config"]["all_gather"] = {"avg_ms": round(g_ms, 4), "of": "the last %d gathers" % len(gather_ms),
+            res["config"]["all_gather"] = {"avg_ms": round(g_ms, 4),
+                                           "of": "the timed gathers" if sg else "the last %d gathers" % len(gather_ms),
                                            "bytes_per_rank": int(outs[0].numel() * 2),
                                            "share_of_step": round(g_ms / (dt / args.steps * 1e3), 4),
                                            "own_shard_in_gathered": ok,
+                                           "path": gather_path,
                                            "note": "ddc_allgather_decimated_dev: ncclAllGather on a second stream, "
+                                                   "overlapped with the next step's compute" if not sg else
+                                                   "all_gather_into_tensor on a second stream (ua3reo_ddc/shard.py), "
                                                    "overlapped with the next step's compute"}
         if not args.no_cpu_baseline and world == 1:
             want = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1)

@@ -172,6 +172,33 @@ def test_fft_frames_within_tolerance(ddc, orc):
     assert (rows[0, -1] >> 11).max() == 31  # something red on the carrier
 
 
+def test_fft_seventy_channels_equal_one_channel_runs(ddc, orc):
+    """Two workgroups of the no-zoom prefilter, the second partly filled, channels with and without
+    the notch and the I/Q swap side by side: every checked channel must equal, bit for bit, the
+    same channel run alone, and stay within the FFT tolerance of the oracle."""
+    n_ch, frames = 70, 3
+    n = 512 * frames
+    spec = np.stack([sig.noisy_two_tone(n, 900 + c, amp=300.0 + 40.0 * c) for c in range(n_ch)])
+    kws = [dict(fft_averaging=1 + c % 4, iq_swap=int(c % 3 == 0), notch=int(c % 5 == 0)) for c in range(n_ch)]
+    d = ddc.Ddc(n_ch)
+    for c, kw in enumerate(kws):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    b1, r1 = d.fft_process(spec[:, :512])
+    b2, r2 = d.fft_process(spec[:, 512:])
+    bins, rows = np.concatenate([b1, b2], axis=1), np.concatenate([r1, r2], axis=1)
+    for c in (0, 1, 5, 15, 63, 64, 65, 69):
+        one = ddc.Ddc(1)
+        one.audio_configure(ddc.audio_params(**kws[c]), 0)
+        wb, wr = one.fft_process(spec[c:c + 1])
+        assert np.array_equal(bins[c], wb[0]) and np.array_equal(rows[c], wr[0]), "channel %d" % c
+        assert np.array_equal(d.fft_waterfall(c), one.fft_waterfall(0)), "channel %d" % c
+        one.close()
+        a = orc.Audio(orc.audio_params(**kws[c]))
+        for f in range(frames):
+            ob, _, _ = a.fft(spec[c, 512 * f:512 * (f + 1)])
+            assert np.abs(bins[c, f] - ob).max() <= 1e-4 * max(float(ob.max()), 1e-3), "channel %d frame %d" % (c, f)
+
+
 def mic_signal(n, seed):
     r = np.random.default_rng(seed)
     t = np.arange(n) / sig.FS

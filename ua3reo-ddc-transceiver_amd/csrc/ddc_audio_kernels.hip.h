@@ -763,19 +763,20 @@ __global__ __launch_bounds__(64) void ddc_audio_rx_demod(AudioState *__restrict_
 
 /* ---- FFT panadapter ---------------------------------------------------------- */
 
-/* Pass A (lane = one branch, I or Q, of one channel): DC filter and optional notch
- * over the call's frames of 512 SPEC samples, in sequence; the two branches never
+/* Pass A with zoom (lane = one branch, I or Q, of one channel): DC filter and optional
+ * notch over the call's frames of 512 SPEC samples, in sequence; the two branches never
  * meet before the FFT, so they run in neighbouring lanes.  The work buffer is
- * planar: work[channel][branch][work_pitch] floats.  Without zoom the samples
- * go to [n]; with zoom M the stream is low-passed (4 biquads), decimated by M
- * (4-tap FIR) and appended behind the 512 - 512/M samples kept from earlier
- * frames: [512 - 512/M + n/M], where FFT frame f is the 512 samples starting at
- * f * 512/M (the firmware's sliding FFTInput_ZOOMFFT buffer). */
+ * planar: work[channel][branch][work_pitch] floats.  The stream is low-passed
+ * (4 biquads), decimated by M (4-tap FIR) and appended behind the 512 - 512/M samples
+ * kept from earlier frames: [512 - 512/M + n/M], where FFT frame f is the 512 samples
+ * starting at f * 512/M (the firmware's sliding FFTInput_ZOOMFFT buffer).  Without zoom
+ * the samples go to [n]: ddc_fft_prefilter_tiled below. */
 template <uint32_t M>
 __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__ states, ZoomState *__restrict__ zooms,
                                                         uint32_t n_ch, const int16_t *__restrict__ spec_iq, uint32_t n,
                                                         float *__restrict__ work, uint32_t work_pitch)
 {
+    static_assert(M > 1, "zoom factors only");
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ch = id >> 1, q = id & 1u; // q = 0: I branch, 1: Q branch
     if (ch >= n_ch) return;
@@ -793,8 +794,8 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
     float *dst = work + ((size_t)ch * 2 + q) * work_pitch;
     const float A1 = 0.99951171875f;
     float zc[20], zf[4], bs[16], w[4]; // w: the newest four low-passed samples
-    constexpr uint32_t keep = M > 1 ? 512 - 512 / M : 0;
-    if (M > 1) {
+    constexpr uint32_t keep = 512 - 512 / M;
+    {
         float *bq = q ? z.bq_q : z.bq_i, *dec = q ? z.dec_q : z.dec_i;
         for (int i = 0; i < 20; i++) zc[i] = z.c[i];
         for (int i = 0; i < 4; i++) zf[i] = z.fir[i];
@@ -818,13 +819,11 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
     auto trip = [&](const uint4 (&in4)[4], const uint32_t i0, auto with_notch) {
         const uint32_t in[16] = { in4[0].x, in4[0].y, in4[0].z, in4[0].w, in4[1].x, in4[1].y, in4[1].z, in4[1].w,
                                   in4[2].x, in4[2].y, in4[2].z, in4[2].w, in4[3].x, in4[3].y, in4[3].z, in4[3].w };
-        float out[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             float f = (float)(int)__builtin_amdgcn_sbfe(in[k], half_off, 16u); // the builtin is typed unsigned
             { const float d = f - dx; const float a = A1 * dy; const float o = d + a; dx = f; dy = o; f = o; }
             if (decltype(with_notch)::value) { if (notch) f = biquad_step(c, nd, f); }
-            if (M == 1) { out[k] = f; continue; }
 #pragma unroll
             for (int sg = 0; sg < 4; sg++) { // arm_biquad_cascade_df1_f32: b0 x + b1 x1 + b2 x2 + a1 y1 + a2 y2
                 const float b0 = zc[5 * sg], b1 = zc[5 * sg + 1], b2 = zc[5 * sg + 2], a1 = zc[5 * sg + 3], a2 = zc[5 * sg + 4];
@@ -839,11 +838,6 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
                 for (int kk = 0; kk < 4; kk++) acc += w[kk] * zf[kk];
                 dst[keep + (i0 + k) / M] = acc;
             }
-        }
-        if (M == 1) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                reinterpret_cast<float4 *>(dst + i0)[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
         }
     };
     for (uint32_t i0 = 0; i0 < n; i0 += 16 * kRing) {
@@ -863,7 +857,7 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
     }
     s.dc_x[4 + q] = dx; s.dc_y[4 + q] = dy;
     if (notch) { nsave[0] = nd[0]; nsave[1] = nd[1]; }
-    if (M > 1) {
+    {
         float *bq = q ? z.bq_q : z.bq_i, *dec = q ? z.dec_q : z.dec_i;
         for (int i = 0; i < 16; i++) bq[i] = bs[i];
         for (int i = 0; i < 3; i++) dec[i] = w[i + 1];
@@ -871,6 +865,195 @@ __global__ __launch_bounds__(64) void ddc_fft_prefilter(AudioState *__restrict__
         for (uint32_t i = 0; i < keep; i++) {
             if (q) z.hist[i].y = dst[produced + i]; else z.hist[i].x = dst[produced + i];
         }
+    }
+}
+
+/* Pass A without zoom: the same DC filter (and optional notch) as ddc_fft_prefilter<1>, laid
+ * out so that the recursion is all its lanes do.  A workgroup of four waves takes 16 channels
+ * (few per workgroup: the work is one dependent chain per channel and branch, so it wants many
+ * compute units, not full ones), tile after tile of 64 samples:
+ *   waves 1 and 2 (loaders) fetch the packed SPEC words, whole 128-byte lines and several tiles
+ *     ahead, and turn them into the filter's first difference x[n] - x[n-1] per branch (both
+ *     are 16-bit integers, so the difference is exact in integers as it is in floats), written
+ *     to an LDS tile as floats;
+ *   wave 0 (lanes 0..15 the I branches, 16..31 the Q branches of the 16 channels) runs
+ *     y = d + A y (and the notch biquad where it is on) over its row of the tile, in place;
+ *   wave 3 writes the finished tile of the step before to the work buffer, whole lines again.
+ * Four tiles rotate through these roles (filled two steps ahead, so that the recursion wave can
+ * fetch its next row while it works on the current one); rows are 68 floats apart, which
+ * spreads the lanes' 16-byte accesses over all banks. */
+constexpr int kPfCh = 16, kPfTile = 64, kPfPitch = 68, kPfAhead = 4, kPfThreads = 4 * 64;
+
+__global__ __launch_bounds__(kPfThreads) void ddc_fft_prefilter_tiled(AudioState *__restrict__ states, uint32_t n_ch,
+                                                                      const int16_t *__restrict__ spec_iq, uint32_t n,
+                                                                      float *__restrict__ work, uint32_t work_pitch)
+{
+    constexpr int kP4 = kPfPitch / 4;  // row pitch in 16-byte units
+    constexpr int kPieces = kPfTile / 4; // 16-byte pieces per row of a tile: 16, one DPP row of lanes
+    static_assert(kPieces == 16 && kPfCh == 16, "lane maps below");
+    __shared__ float4 tile[4][2][kPfCh * kP4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t ch0 = blockIdx.x * kPfCh;
+    const uint32_t n_tiles = n / kPfTile; // n is a multiple of 512, so n_tiles is one of 8
+    const uint32_t mrow = lane >> 4, mpiece = lane & 15u; // loaders and the writer: 16 bytes of a row each
+
+    if (wave == 1 || wave == 2) {
+        // ---- loaders: 8 rows each, two 16-byte fetches per lane and tile
+        const uint4 *src[2];
+        uint32_t row[2], swap[2], last_w[2] = { 0, 0 }, final_w[2] = { 0, 0 };
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            row[i] = (wave - 1u) * 8u + (uint32_t)i * 4u + mrow;
+            const uint32_t chan = ch0 + row[i] < n_ch ? ch0 + row[i] : n_ch - 1u; // rows past the end repeat the last channel
+            src[i] = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(spec_iq) + (size_t)chan * n) + mpiece;
+            swap[i] = states[chan].p.iq_swap ? 16u : 0u;
+        }
+        uint4 ring[kPfAhead][2]; // slot u % kPfAhead holds tile u; tiles past the end repeat the last one
+        auto fetch = [&](uint32_t t, uint4 (&v)[2]) {
+            const uint32_t tt = t < n_tiles ? t : n_tiles - 1u;
+#pragma unroll
+            for (int i = 0; i < 2; i++) v[i] = src[i][(size_t)tt * kPieces];
+        };
+        auto emit = [&](const uint4 (&v)[2], uint32_t t, uint32_t buf) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                // I in the low half whatever the channel's I/Q swap
+                const uint32_t w[4] = { __builtin_amdgcn_alignbit(v[i].x, v[i].x, swap[i]), __builtin_amdgcn_alignbit(v[i].y, v[i].y, swap[i]),
+                                        __builtin_amdgcn_alignbit(v[i].z, v[i].z, swap[i]), __builtin_amdgcn_alignbit(v[i].w, v[i].w, swap[i]) };
+                // the word before this lane's four: the neighbour's last one, or for the first piece of a row
+                // the last word of the row's tile before (held by the lane fifteen up)
+                const uint32_t from_nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], 0x111, 0xF, 0xF, false);       // row_shr:1
+                const uint32_t from_tile = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last_w[i], 0x10F, 0xF, 0xF, false); // row_shl:15
+                const uint32_t before = mpiece == 0u ? from_tile : from_nb;
+                last_w[i] = w[3];
+                if (t == n_tiles - 1u) final_w[i] = w[3];
+                const uint32_t p[5] = { before, w[0], w[1], w[2], w[3] };
+                float di[4], dq[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    di[e] = (float)((int)(int16_t)(p[e + 1] & 0xFFFFu) - (int)(int16_t)(p[e] & 0xFFFFu));
+                    dq[e] = (float)(((int)p[e + 1] >> 16) - ((int)p[e] >> 16));
+                }
+                tile[buf][0][row[i] * kP4 + mpiece] = make_float4(di[0], di[1], di[2], di[3]);
+                tile[buf][1][row[i] * kP4 + mpiece] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            }
+        };
+        fetch(0, ring[0]);
+        fetch(1, ring[1]);
+        emit(ring[0], 0, 0);
+        emit(ring[1], 1, 1);
+#pragma unroll
+        for (int u = 2; u < 2 + kPfAhead; u++) fetch((uint32_t)u, ring[u % kPfAhead]);
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kPfAhead) {
+#pragma unroll
+            for (int u = 0; u < kPfAhead; u++) {
+                const uint32_t t = t0 + (uint32_t)u;
+                const int slot = (u + 2) % kPfAhead; // tile t + 2 (a constant once the loop is unrolled)
+                emit(ring[slot], t + 2u, (t + 2u) & 3u);
+                fetch(t + 2u + kPfAhead, ring[slot]);
+                __syncthreads();
+            }
+        }
+        // the new x[n-1] of both branches: the last word of a row sits with the lane of its last piece
+        if (mpiece == kPieces - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (ch0 + row[i] >= n_ch) continue;
+                AudioState &s = states[ch0 + row[i]];
+                s.dc_x[4] = (float)(int)(int16_t)(final_w[i] & 0xFFFFu);
+                s.dc_x[5] = (float)((int)final_w[i] >> 16);
+            }
+        }
+        return;
+    }
+
+    if (wave == 3) {
+        // ---- writer: the tile finished in the step before, 2 x 16 rows x 256 bytes
+        __syncthreads();
+        for (uint32_t t = 0; t <= n_tiles; t++) {
+            const uint32_t buf = (t - 1u) & 3u;
+            if (t > 0) {
+                float4 v[8]; // all LDS reads first, so that their latency is paid once
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t q = (uint32_t)i >> 2, r = ((uint32_t)i & 3u) * 4u + mrow;
+                    v[i] = tile[buf][q][r * kP4 + mpiece];
+                }
+                // (the values are pinned to registers here: otherwise each read sinks into its store's
+                // conditional block and the LDS latencies line up one behind the other)
+#pragma unroll
+                for (int i = 0; i < 8; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t q = (uint32_t)i >> 2, r = ((uint32_t)i & 3u) * 4u + mrow;
+                    if (ch0 + r < n_ch)
+                        reinterpret_cast<float4 *>(work + ((size_t)(ch0 + r) * 2 + q) * work_pitch + (size_t)(t - 1u) * kPfTile)[mpiece] = v[i];
+                }
+            }
+            if (t < n_tiles) __syncthreads();
+        }
+        return;
+    }
+
+    // ---- the recursion: lanes 0..15 = I branches, 16..31 = Q branches of the 16 channels
+    const uint32_t q = (lane >> 4) & 1u, crow = lane & 15u;
+    const uint32_t ch = ch0 + crow;
+    const bool live = lane < 32u && ch < n_ch;
+    AudioState &s = states[ch < n_ch ? ch : n_ch - 1u];
+    const float A1 = 0.99951171875f;
+    const float dx = s.dc_x[4 + q];
+    float dy = s.dc_y[4 + q];
+    float *nsave = q ? s.notch_fq : s.notch_fi;
+    float nd[2] = { nsave[0], nsave[1] };
+    float c[5];
+    for (int i = 0; i < 5; i++) c[i] = s.notch_c[i];
+    const bool notch = live && s.p.notch;
+    const bool any_notch = __any(notch);
+    __syncthreads();
+    // the loaders took the sample before the call as 0: put the filter's own x[n-1] in its place
+    const bool work_lane = lane < 32u;
+    float4 rows[2][kPieces]; // the row being filtered and the next one, fetched while the first is worked on
+    if (work_lane) {
+        float4 &first = tile[0][q][crow * kP4];
+        first.x = first.x - dx;
+#pragma unroll
+        for (int k4 = 0; k4 < kPieces; k4++) rows[0][k4] = tile[0][q][crow * kP4 + k4];
+    }
+    auto step = [&](float4 (&cur)[kPieces], float4 (&nxt)[kPieces], uint32_t t, auto with_notch) {
+        if (work_lane) {
+            float4 *rowp = &tile[t & 3u][q][crow * kP4];
+            const float4 *nextp = &tile[(t + 1u) & 3u][q][crow * kP4]; // filled in the step before
+#pragma unroll
+            for (int k4 = 0; k4 < kPieces; k4++) nxt[k4] = nextp[k4];
+#pragma unroll
+            for (int k4 = 0; k4 < kPieces; k4++) {
+                const float d[4] = { cur[k4].x, cur[k4].y, cur[k4].z, cur[k4].w };
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = A1 * dy;
+                    dy = d[e] + a;
+                    o[e] = dy;
+                    if (decltype(with_notch)::value) { if (notch) o[e] = biquad_step(c, nd, o[e]); }
+                }
+                rowp[k4] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+    };
+    for (uint32_t t = 0; t < n_tiles; t += 2) { // n_tiles is even
+        if (any_notch) {
+            step(rows[0], rows[1], t, std::true_type{});
+            step(rows[1], rows[0], t + 1u, std::true_type{});
+        } else {
+            step(rows[0], rows[1], t, std::false_type{});
+            step(rows[1], rows[0], t + 1u, std::false_type{});
+        }
+    }
+    if (live) {
+        s.dc_y[4 + q] = dy;
+        if (notch) { nsave[0] = nd[0]; nsave[1] = nd[1]; }
     }
 }
 
@@ -937,35 +1120,60 @@ __device__ inline uint16_t fft_color(int height)
     return (uint16_t)(((red & 0xF8) << 8) | ((green & 0xFC) << 3) | (blue >> 3));
 }
 
-/* Pass C (workgroup of 256 = one channel, sequential over its frames): auto-level,
- * normalise, temporal smoothing, then the waterfall row (fft-shifted RGB565) and
- * the over-range count that feeds the next frame's auto-level. */
-__global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ states, const float *__restrict__ mags,
-                                                     uint32_t frames_per_ch, float *__restrict__ bins,
-                                                     uint16_t *__restrict__ rows, uint16_t *__restrict__ wtf)
+/* Pass C (one wave = one channel, sequential over its frames; a lane owns four neighbouring
+ * bins): auto-level, normalise, temporal smoothing, then the waterfall row (fft-shifted
+ * RGB565) and the over-range count that feeds the next frame's auto-level.  The frame
+ * maximum and the count are wave reductions, so a frame costs no barrier, and the waterfall
+ * is updated in the same pass. */
+__global__ __launch_bounds__(64) void ddc_fft_level(AudioState *__restrict__ states, const float *__restrict__ mags,
+                                                    uint32_t frames_per_ch, float *__restrict__ bins,
+                                                    uint16_t *__restrict__ rows, uint16_t *__restrict__ wtf)
 {
-    __shared__ float red[256];
-    __shared__ uint32_t errs;
-    __shared__ float s_max_value;
-    const uint32_t ch = blockIdx.x, x = threadIdx.x;
+    __shared__ uint16_t colour[32]; // fft_color of the 30 heights a pixel can have
+    const uint32_t ch = blockIdx.x, x0 = threadIdx.x * 4u;
+    if (threadIdx.x < 32u) colour[threadIdx.x] = fft_color((int)threadIdx.x);
+    __syncthreads();
     AudioState &s = states[ch];
-    float mean = s.fft_mean[x];
+    float mean[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) mean[k] = s.fft_mean[x0 + k];
     float max_value = s.fft_max_value;
     uint32_t max_errors = s.fft_max_errors;
     const float avg = (float)s.p.fft_averaging;
     const bool loopback = s.p.mode == DDC_MODE_LOOPBACK;
-    for (uint32_t f = 0; f < frames_per_ch; f++) {
-        const size_t fr = (size_t)ch * frames_per_ch + f;
-        const float v = mags[fr * 256 + x];
-        red[x] = v;
-        if (x == 0) errs = 0;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if ((int)x < st) red[x] = fmaxf(red[x], red[x + st]);
-            __syncthreads();
-        }
-        if (x == 0) {
-            const float mx = red[0];
+    // the caller's buffers take 16-byte / 8-byte stores when they are aligned for them
+    const bool wide = ((reinterpret_cast<uintptr_t>(bins) & 15u) | (reinterpret_cast<uintptr_t>(rows) & 7u)) == 0;
+    const uint32_t nx0 = x0 < 128u ? x0 + 128u : x0 - 128u; // fft shift; four neighbours stay neighbours
+    const size_t fr0 = (size_t)ch * frames_per_ch;
+    // the magnitudes are fetched four frames ahead of the frame being levelled
+    float4 ahead[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++)
+        ahead[j] = j < frames_per_ch ? reinterpret_cast<const float4 *>(mags + (fr0 + j) * 256 + x0)[0] : make_float4(0, 0, 0, 0);
+    // waterfall (wtf_buffer, fft.c:353-376): every frame scrolls the picture down by one row and lands
+    // on top, so after this call's F frames the old rows sit F lower.  They move first (all loads, then
+    // all stores: a lane only ever touches its own four columns); the new rows are stored as they are made.
+    const uint32_t F = frames_per_ch < 50u ? frames_per_ch : 50u;
+    uint16_t *w = wtf + (size_t)ch * 50 * 256;
+    {
+        uint2 old[50];
+#pragma unroll
+        for (uint32_t y = 0; y < 50; y++)
+            if (y + F < 50u) old[y] = reinterpret_cast<const uint2 *>(w + y * 256 + x0)[0];
+#pragma unroll
+        for (uint32_t y = 0; y < 50; y++)
+            if (y + F < 50u) reinterpret_cast<uint2 *>(w + (y + F) * 256 + x0)[0] = old[y];
+    }
+    for (uint32_t f0 = 0; f0 < frames_per_ch; f0 += 4)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t f = f0 + j;
+        if (f >= frames_per_ch) break;
+        const size_t fr = fr0 + f;
+        const float v[4] = { ahead[j].x, ahead[j].y, ahead[j].z, ahead[j].w };
+        if (f + 4 < frames_per_ch) ahead[j] = reinterpret_cast<const float4 *>(mags + (fr + 4) * 256 + x0)[0];
+        const float mx = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        {
             const float diff = (mx - max_value) / 10.0f;
             const uint32_t e = max_errors;
             float mv = max_value;
@@ -976,33 +1184,41 @@ __global__ __launch_bounds__(256) void ddc_fft_level(AudioState *__restrict__ st
             else if (e <= 1 && mv > 1.0f) mv -= 1.0f;
             if (mv < 100.0f) mv = 100.0f;
             if (loopback) mv = 60000;
-            s_max_value = mv;
+            max_value = mv;
         }
-        __syncthreads();
-        max_value = s_max_value;
-        const float xn = v * (1.0f / max_value);
-        if (mean < xn) mean += (xn - mean) / avg;
-        else mean -= (mean - xn) / avg;
-        if (bins) bins[fr * 256 + x] = mean;
-        const int nx = x < 128 ? x + 128 : x - 128;
-        int h = (int)(uint16_t)f2i_sat(mean * 30);
-        uint16_t c;
-        if (h > 29) { c = 0xF800; atomicAdd(&errs, 1u); }
-        else c = fft_color(h);
-        rows[fr * 256 + nx] = c;
-        __syncthreads();
+        const float inv = 1.0f / max_value;
+        uint16_t c[4];
+        uint32_t errs = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float xn = v[k] * inv;
+            if (mean[k] < xn) mean[k] += (xn - mean[k]) / avg;
+            else mean[k] -= (mean[k] - xn) / avg;
+            const int h = (int)(uint16_t)f2i_sat(mean[k] * 30);
+            const bool over = h > 29;
+            errs += (uint32_t)__popcll(__ballot(over));
+            c[k] = over ? (uint16_t)0xF800 : colour[h & 31];
+        }
         max_errors = errs;
-        __syncthreads();
+        const uint2 px = make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16));
+        if (wide) {
+            if (bins) reinterpret_cast<float4 *>(bins + fr * 256 + x0)[0] = make_float4(mean[0], mean[1], mean[2], mean[3]);
+            reinterpret_cast<uint2 *>(rows + fr * 256 + nx0)[0] = px;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (bins) bins[fr * 256 + x0 + k] = mean[k];
+                rows[fr * 256 + nx0 + k] = c[k];
+            }
+        }
+        // the pixels of this lane's own columns in the shifted row were made by the lane half a wave away
+        const uint2 mine = make_uint2((uint32_t)__shfl_xor((int)px.x, 32, 64), (uint32_t)__shfl_xor((int)px.y, 32, 64));
+        const uint32_t y = frames_per_ch - 1u - f; // the last frame is row 0
+        if (y < 50u) reinterpret_cast<uint2 *>(w + y * 256 + x0)[0] = mine;
     }
-    s.fft_mean[x] = mean;
-    if (x == 0) { s.fft_max_value = max_value; s.fft_max_errors = max_errors; }
-    // waterfall (wtf_buffer, fft.c:353-376): every frame scrolls the picture down by one
-    // row and lands on top; after F frames the old rows sit F lower
-    __syncthreads();
-    const uint32_t F = frames_per_ch < 50u ? frames_per_ch : 50u;
-    uint16_t *w = wtf + (size_t)ch * 50 * 256;
-    for (int y = 49; y >= (int)F; y--) w[y * 256 + x] = w[(y - (int)F) * 256 + x];
-    for (uint32_t y = 0; y < F; y++) w[y * 256 + x] = rows[((size_t)ch * frames_per_ch + (frames_per_ch - 1 - y)) * 256 + x];
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.fft_mean[x0 + k] = mean[k];
+    if (threadIdx.x == 0) { s.fft_max_value = max_value; s.fft_max_errors = max_errors; }
 }
 
 /* FFT_moveWaterfall (fft.c:453-503): on a retune the waterfall moves sideways by

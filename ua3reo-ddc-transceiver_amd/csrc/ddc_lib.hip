@@ -1513,7 +1513,10 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
 #define DDC_PREFILTER(Z) hipLaunchKernelGGL(ddc::ddc_fft_prefilter<Z>, grid, block, 0, ctx->stream, ctx->d_audio, \
                                             ctx->d_zoom, (uint32_t)nch, spec_iq, (uint32_t)n_frames, work, (uint32_t)pitch)
         switch (M) {
-        case 1: DDC_PREFILTER(1); break;
+        case 1: // no zoom: the tiled form (recursion lanes fed through LDS by loader and writer waves)
+            hipLaunchKernelGGL(ddc::ddc_fft_prefilter_tiled, dim3((unsigned)((nch + ddc::kPfCh - 1) / ddc::kPfCh)), dim3(ddc::kPfThreads), 0,
+                               ctx->stream, ctx->d_audio, (uint32_t)nch, spec_iq, (uint32_t)n_frames, work, (uint32_t)pitch);
+            break;
         case 2: DDC_PREFILTER(2); break;
         case 4: DDC_PREFILTER(4); break;
         case 8: DDC_PREFILTER(8); break;
@@ -1525,7 +1528,7 @@ int ddc_fft_process_dev(ddc_ctx *ctx, const int16_t *spec_iq, size_t n_frames, f
     hipLaunchKernelGGL(ddc::ddc_fft_frames, dim3((unsigned)(nch * fpc)), dim3(64), 0, ctx->stream,
                        reinterpret_cast<const float *>(ctx->d_fft_work),
                        (uint32_t)fpc, (uint32_t)pitch, zw, ctx->d_fft_mag);
-    hipLaunchKernelGGL(ddc::ddc_fft_level, dim3((unsigned)nch), dim3(256), 0, ctx->stream, ctx->d_audio, ctx->d_fft_mag,
+    hipLaunchKernelGGL(ddc::ddc_fft_level, dim3((unsigned)nch), dim3(64), 0, ctx->stream, ctx->d_audio, ctx->d_fft_mag,
                        (uint32_t)fpc, bins, rows ? rows : ctx->d_fft_rows, ctx->d_wtf);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
