@@ -7,9 +7,10 @@
  * CMSIS-DSP 1.6.0 library (Keil pack ARM.CMSIS 5.5.1, not in the reference
  * tree).  The arm_* routines below restate the published CMSIS-DSP algorithms
  * (lattice-ladder IIR, transposed direct form II biquad, normalised LMS,
- * complex FFT + magnitude) in their documented operation order; table-based
- * arm_sin/cos_f32 are replaced by libm, which is why float results carry a
- * tolerance instead of bit equality.
+ * complex FFT + magnitude, table-interpolated arm_sin/cos_f32) in their documented
+ * operation order; the complex FFT is a radix-2 one in double precision, not the
+ * library's radix-8 in float, which is why FFT results carry a tolerance instead of
+ * bit equality.
  *
  * Build with -ffp-contract=off: every float operation rounds on its own.
  */
@@ -39,6 +40,25 @@ typedef struct {
 } orc_audio_params_t;
 
 /* ---- CMSIS-DSP restatements ------------------------------------------------ */
+
+/* arm_sin_f32 / arm_cos_f32 (CMSIS-DSP 1.6.0 FastMathFunctions): x in radians is scaled
+ * to turns, the fraction of a turn times 512 gives a table index and a remainder, and the
+ * result is the linear interpolation of two neighbouring entries of sinTable_f32[513]. */
+static float arm_table_lookup(float in)
+{
+    int32_t n = (int32_t)in;
+    if (in < 0.0f) n--;              /* floor */
+    in = in - (float)n;
+    float findex = 512.0f * in;
+    uint16_t index = (uint16_t)findex;
+    if (index >= 512) { index = 0; findex -= 512.0f; }
+    const float fract = findex - (float)index;
+    const float a = arm_sin_table[index], b = arm_sin_table[index + 1];
+    return (1.0f - fract) * a + fract * b;
+}
+float orc_arm_sin_f32(float x) { return arm_table_lookup(x * 0.159154943092f); }
+float orc_arm_cos_f32(float x) { return arm_table_lookup(x * 0.159154943092f + 0.25f); }
+const float *orc_arm_sin_table(void) { return arm_sin_table; }
 
 /* arm_iir_lattice_f32: N stages, reversed reflection (k) and ladder (v) tables,
  * state g[0..N-1] = backward residuals of the previous sample, newest stage first. */
@@ -203,7 +223,7 @@ int orc_audio_configure(orc_audio_t *s, const orc_audio_params_t *p)
     s->agc_down = s->agc_up / 10.0f;
     /* CWDecoder_Init: k = (int)(0.5 + 192*350/48000) = 1 */
     const float omega = (float)((2.0 * PI_F * 1) / 192);
-    s->cw_coeff = (float)(2.0 * cosf(omega));
+    s->cw_coeff = (float)(2.0 * orc_arm_cos_f32(omega));
     s->cw_limit = 50; s->cw_limit_low = 50;
     memset(s->cw_text, ' ', 15);
     s->cw_text[15] = 0;
@@ -613,8 +633,8 @@ void orc_audio_tx_block(orc_audio_t *s, const int16_t *mic_lr, int16_t *iq_out, 
                 s->txfm_accum = f2u_sat((float)s->txfm_accum + s->txfm_hpf_b);
                 s->txfm_accum %= 48000u;
                 const float sd = (s->txfm_accum / (float)48000) * PI_F * s->txfm_index;
-                bi[i] = amp * sinf(sd);
-                bq[i] = amp * cosf(sd);
+                bi[i] = amp * orc_arm_sin_f32(sd);
+                bq[i] = amp * orc_arm_cos_f32(sd);
             }
             break;
         default: break;
@@ -781,7 +801,7 @@ void orc_fft_frame(orc_audio_t *s, const int16_t *spec_iq, float *bins, uint16_t
     }
     double re[FFT_SIZE], im[FFT_SIZE];
     for (int i = 0; i < FFT_SIZE; i++) {
-        const float w = 0.54f - 0.46f * cosf((2.0f * PI_F * i) / ((float)FFT_SIZE - 1.0f));
+        const float w = 0.54f - 0.46f * orc_arm_cos_f32((2.0f * PI_F * i) / ((float)FFT_SIZE - 1.0f));
         re[i] = (double)(w * fi[i]);
         im[i] = (double)(w * fq[i]);
     }

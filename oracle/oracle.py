@@ -45,6 +45,11 @@ def lib():
         L.orc_rx_chain_run.restype = C.c_size_t
         L.orc_phrase_from_freq.restype = C.c_uint32
         L.orc_freq_from_phrase.restype = C.c_uint32
+        L.orc_arm_sin_f32.restype = C.c_float
+        L.orc_arm_sin_f32.argtypes = [C.c_float]
+        L.orc_arm_cos_f32.restype = C.c_float
+        L.orc_arm_cos_f32.argtypes = [C.c_float]
+        L.orc_arm_sin_table.restype = C.POINTER(C.c_float)
         L.orc_init()
     return _lib
 
@@ -464,3 +469,16 @@ def fast_rx_front(phi, adc):
     f.restype = C.c_size_t
     f(C.c_uint32(int(phi)), _p(adc), C.c_size_t(n), _p(oi), _p(oq))
     return oi, oq
+
+
+def arm_sin_f32(x):
+    """arm_sin_f32 of CMSIS-DSP as the oracle restates it (513-entry table, linear interpolation)."""
+    return float(lib().orc_arm_sin_f32(float(x)))
+
+
+def arm_cos_f32(x):
+    return float(lib().orc_arm_cos_f32(float(x)))
+
+
+def arm_sin_table():
+    return np.ctypeslib.as_array(lib().orc_arm_sin_table(), shape=(513,)).copy()

@@ -119,3 +119,28 @@ def test_oracle_impulse_responses_replay_the_reference_taps(orc):
     y = orc.TxCicComp().run(x)            # interleaved phase 1 / phase 2 outputs
     assert list(y[0:48:2]) == [int(v) for v in REF["tx_ciccomp_phase1"]]
     assert list(y[1:48:2]) == [int(v) for v in REF["tx_ciccomp_phase2"]]
+
+
+def test_arm_sin_table_and_interpolation_on_both_sides(ddc, orc):
+    """arm_sin_f32 / arm_cos_f32 are CMSIS-DSP routines (1.6.0, not part of the reference tree):
+    parity unpinned.  What can be held: both sides build the same 513-entry table (the float of
+    the 8-decimal literal of sin(2 pi i / 512)) from their own generators, the table has the
+    library's landmarks, and the interpolated value stays within the table's interpolation
+    error of the true sine and is exact at table points."""
+    lib_t, orc_t = ddc.debug_table("arm_sin", np.float32), orc.arm_sin_table()
+    assert lib_t.shape == (513,) and np.array_equal(lib_t.view(np.uint32), orc_t.view(np.uint32))
+    assert lib_t[0] == 0 and lib_t[128] == 1 and lib_t[384] == -1 and lib_t[256] == 0
+    assert np.signbit(lib_t[512]) and lib_t[512] == 0          # -0.00000000f
+    assert lib_t[1] == np.float32(0.01227154) and lib_t[511] == np.float32(-0.01227154)
+    true = np.sin(2 * np.pi * np.arange(513) / 512)
+    assert np.abs(lib_t - true).max() <= 0.5e-8 + 6e-8          # 8 decimals, then float rounding
+    xs = np.linspace(-7.0, 14.0, 4001).astype(np.float32)
+    s = np.array([orc.arm_sin_f32(x) for x in xs])
+    c = np.array([orc.arm_cos_f32(x) for x in xs])
+    bound = (2 * np.pi / 512) ** 2 / 8 + 3e-6                   # chord error of a 512-point table
+    assert np.abs(s - np.sin(xs.astype(np.float64))).max() <= bound
+    assert np.abs(c - np.cos(xs.astype(np.float64))).max() <= bound
+    for i in (0, 1, 100, 128, 300, 511):
+        x = np.float32(i / 512.0) / np.float32(0.159154943092)
+        assert abs(orc.arm_sin_f32(x) - float(lib_t[i])) <= 2e-6
+    assert orc.arm_sin_f32(0.0) == 0.0 and orc.arm_cos_f32(0.0) == 1.0

@@ -38,6 +38,34 @@ constexpr int kABlock = 192;
 constexpr int kASub = 64;
 constexpr float kPiF = 3.14159265358979f;
 
+/* arm_sin_f32 / arm_cos_f32 of CMSIS-DSP 1.6.0 (the library the firmware links; its source is
+ * not part of the reference tree, the algorithm is the published one): the angle scaled to turns,
+ * its fraction times 512 split into a table index and a remainder, linear interpolation between
+ * two entries of a 513-entry sine table.  The table is built by the host (ddc_lib.hip,
+ * arm_sin_table) and uploaded when a ctx is created.  T is that table. */
+template <typename T>
+__host__ __device__ __forceinline__ float arm_sin_interp(const T &table, float in)
+{
+    int32_t n = (int32_t)in;
+    if (in < 0.0f) n--;
+    in = in - (float)n;
+    float findex = 512.0f * in;
+    uint32_t index = (uint32_t)(uint16_t)findex;
+    if (index >= 512u) { index = 0; findex -= 512.0f; }
+    const float fract = findex - (float)index;
+    const float a = table[index], b = table[index + 1];
+    return (1.0f - fract) * a + fract * b;
+}
+template <typename T> __host__ __device__ __forceinline__ float arm_sin_with(const T &table, float x)
+{
+    return arm_sin_interp(table, x * 0.159154943092f);
+}
+template <typename T> __host__ __device__ __forceinline__ float arm_cos_with(const T &table, float x)
+{
+    return arm_sin_interp(table, x * 0.159154943092f + 0.25f);
+}
+__device__ float g_arm_sin_table[513]; // written once per device, before any kernel that reads it
+
 struct Lattice {
     float g[12];
 };
@@ -1374,8 +1402,8 @@ __global__ __launch_bounds__(64) void ddc_audio_tx(AudioState *__restrict__ stat
                 fa = oi;
                 facc = f2u_sat((float)facc + fb) % 48000u;
                 const float sd = (facc / (float)48000) * kPiF * fm_index;
-                oi = amp * sinf(sd);
-                oq = amp * cosf(sd);
+                oi = amp * arm_sin_with(g_arm_sin_table, sd);
+                oq = amp * arm_cos_with(g_arm_sin_table, sd);
             }
             if (p.mute) { oi = oi * 0; oq = oq * 0; }
             if (m == DDC_MODE_LOOPBACK) {

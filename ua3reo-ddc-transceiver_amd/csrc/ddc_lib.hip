@@ -20,6 +20,24 @@
 #include "ddc_rx_kernels.hip.h"
 #include "ddc_tx_kernels.hip.h"
 #include "ddc_audio_kernels.hip.h"
+#include <array>
+
+/* sinTable_f32 of CMSIS-DSP: sin(2 pi i / 512), i = 0..512, as the float of its 8-decimal literal
+ * (the form the library's table source is printed in; the last entry reads -0.00000000f). */
+static const std::array<float, 513> &arm_sin_table()
+{
+    static const std::array<float, 513> table = [] {
+        std::array<float, 513> t{};
+        for (int i = 0; i <= 512; i++) {
+            char lit[32];
+            snprintf(lit, sizeof lit, "%.8f", std::sin(2.0 * 3.14159265358979323846 * i / 512.0));
+            t[i] = strtof(lit, nullptr);
+        }
+        return t;
+    }();
+    return table;
+}
+
 
 struct ddc_ctx {
     ddc_config cfg{};
@@ -548,15 +566,17 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
     CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_i, sizeof tx_hilbert_i, 0));
     CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_tx_hilbert), tx_hilbert_q, sizeof tx_hilbert_q, sizeof tx_hilbert_i));
     {
-        // Hamming window as the firmware evaluates it (fft.c:249-251) and the
-        // 512-point twiddles
+        // Hamming window as the firmware evaluates it (fft.c:274-281, with CMSIS's table cosine) and the
+        // 512-point twiddles; the sine table itself for the FM modulator
         std::vector<float> win(512);
         std::vector<float2> tw(256);
-        for (int i = 0; i < 512; i++) win[i] = 0.54f - 0.46f * cosf((2.0f * ddc::kPiF * i) / (512.0f - 1.0f));
+        for (int i = 0; i < 512; i++)
+            win[i] = 0.54f - 0.46f * ddc::arm_cos_with(arm_sin_table(), (2.0f * ddc::kPiF * i) / (512.0f - 1.0f));
         for (int k = 0; k < 256; k++) {
             const double a = -2.0 * 3.14159265358979323846 * k / 512.0;
             tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
+        CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::g_arm_sin_table), arm_sin_table().data(), 513 * sizeof(float)));
         CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_window), win.data(), 512 * sizeof(float)));
         CONST_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ddc::c_fft_twiddle), tw.data(), 256 * sizeof(float2)));
     }
@@ -1304,7 +1324,7 @@ int ddc_audio_configure(ddc_ctx *ctx, int32_t channel, const ddc_audio_params *p
     st.agc_down = st.agc_up / 10.0f;
     { // CWDecoder_Init, cw_decoder.c:41-54: bin k = (int)(0.5 + 192 * 350 / 48000) = 1
         const float omega = (float)((2.0 * ddc::kPiF * 1) / 192);
-        st.cw_coeff = (float)(2.0 * cosf(omega));
+        st.cw_coeff = (float)(2.0 * ddc::arm_cos_with(arm_sin_table(), omega));
         st.cw_limit = 50;
         st.cw_limit_low = 50;
         memset(st.cw_text, ' ', 15);
@@ -1973,6 +1993,7 @@ int ddc_debug_nco(ddc_ctx *ctx, uint32_t first_phase, uint32_t count, int16_t *s
 
 /* ---- the constant tables compiled into this library ---------------------- */
 
+
 int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
 {
     if (!name || !bytes) return -EINVAL;
@@ -2000,6 +2021,7 @@ int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
     TAB("zoom_biquad", kZoomBiquad)
     TAB("zoom_fir", kZoomFir)
 #undef TAB
+    if (k == "arm_sin") { src = arm_sin_table().data(); n = 513 * sizeof(float); }
     if (k == "nco_coarse") {          // as uploaded for the kernels: {2 cc | 2 sc << 16, -2 sc | 2 cc << 16}
         if (build_nco_table(nco) != 0) return fail(nullptr, -EFAULT, "fine-sine shortcut does not reproduce the NCO fine ROM");
         src = nco.data();
