@@ -257,6 +257,63 @@ def test_tx_fm_bit_exact(ddc, orc):
         assert np.abs(iq[c].astype(np.int32)).max() > 1000
 
 
+def test_tx_device_chain_mic_to_dac(ddc, orc):
+    """The whole transmit direction on device pointers: microphone frames -> processTxAudio
+    (ddc_audio_tx_process_dev) -> the FPGA's TX chain (ddc_tx_process_dev) -> DAC words,
+    two calls in a row, against the oracle's two halves chained the same way."""
+    torch = pytest.importorskip("torch")
+    n, n_ch = 192 * 2, 3
+    cases = [dict(mode="USB", rf_power=50), dict(mode="NFM", rf_power=80, filter_width=0), dict(mode="AM", rf_power=40)]
+    phis = [ddc.phrase_from_frequency(f)[0] for f in (7100000, 14200000, 3650000)]
+    mic = np.stack([mic_signal(2 * n, 800 + c) for c in range(n_ch)])
+    d = ddc.Ddc(n_ch)
+    d.tune_many(phis)
+    for c, kw in enumerate(cases):
+        d.audio_configure(ddc.audio_params(**kw), c)
+    mic_d = torch.from_numpy(mic).cuda()
+    iq_d = torch.zeros((n_ch, n, 2), dtype=torch.int16, device="cuda")
+    dac_d = torch.zeros((2, n_ch, 1024 * n), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(2):
+        part = mic_d[:, k * n:(k + 1) * n].contiguous()
+        torch.cuda.synchronize()
+        d.audio_tx_process_dev(part.data_ptr(), n, iq_d.data_ptr())
+        d.tx_process_dev(iq_d.data_ptr(), n, dac_d[k].data_ptr())
+        d.sync()
+    dac = dac_d.cpu().numpy().view(np.uint16)
+    for c, kw in enumerate(cases):
+        wiq, _ = orc.Audio(orc.audio_params(**kw)).tx(mic[c])
+        want = orc.TxChain(phis[c]).run(wiq)
+        assert np.array_equal(np.concatenate([dac[0, c], dac[1, c]]), want), "case %d" % c
+        assert len(set(want.tolist())) > 100
+
+
+def test_audio_stage_runs_single_firmware_stages(ddc, orc):
+    """ddc_audio_stage, the entry the firmware-style shim is built on: the DC filter and the AGC
+    as stages of their own must equal the same stages inside a full processRxAudio run of the
+    oracle only where nothing else touches the samples, so they are checked by their own laws:
+    the DC filter's recursion restated here, and the AGC's block gain never exceeding its limits."""
+    d = ddc.Ddc(1)
+    d.audio_configure(ddc.audio_params(mode="USB", agc=1))
+    r = np.random.default_rng(5)
+    x = (r.normal(0, 3000.0, 192) + 700.0).astype(np.float32)
+    y = d.audio_stage(0, 0, 0, x)                         # dc_filter, state slot 0
+    want = np.zeros(192, np.float32)
+    px, py = np.float32(0), np.float32(0)
+    a1 = np.float32(0.99951171875)
+    for i in range(192):                                  # audio_filters.c:358-373
+        o = np.float32(np.float32(x[i] - px) + np.float32(a1 * py))
+        px, py = x[i], o
+        want[i] = o
+    assert np.array_equal(y, want)
+    y2 = d.audio_stage(0, 0, 0, x)                        # the state carries over
+    assert not np.array_equal(y2, y)
+    g = d.audio_stage(0, 1, 0, x)                         # DoAGC on the block
+    assert np.isfinite(g).all() and np.abs(g).max() <= 10000.0 * 1.0001
+    with pytest.raises(ddc.DdcError):
+        d.audio_stage(0, 9, 0, x)
+
+
 @pytest.mark.parametrize("zoom", [2, 4, 8, 16])
 def test_fft_zoom_within_tolerance(ddc, orc, zoom):
     n_ch, frames = 3, 20
