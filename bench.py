@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-copy-rate", action="store_true", help="skip the device-to-device copy rate in the roofline block")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the config-3 (ddc+fft) and config-4 (tx) shapes that the default run times after the headline")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="time the --steps calls directly behind the warm-up steps (no untimed calls until the clock has settled)")
     ap.add_argument("--shared-stream", action="store_true",
                     help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
                          "reported apart from the headline: the ADC bytes then come from L2, not HBM")
@@ -287,7 +289,9 @@ def main(argv=None):
                 sec[name] = {"workload": r["config"]["workload"], "metric": r["metric"], "value": r["value"], "unit": r["unit"],
                              "steps": r["steps"], "ms_per_step": r["ms_per_step"], "frac": r["roofline"]["frac"],
                              "frac_of_step": r["roofline"]["frac_of_step"], "kernel": r["roofline"]["kernel"],
-                             "parity_check": r["config"]["parity_check"]}
+                             "parity_check": r["config"]["parity_check"],
+                             "first_window_ms_per_step": r["config"]["clock_settle"].get("first_window_ms_per_step"),
+                             "settle_calls": r["config"]["clock_settle"].get("calls")}
             res["secondary"] = sec
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -295,6 +299,41 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def settle_clock(step, sync, torch, dist, dev, enabled, chunk=20, max_chunks=40, tol=0.005):
+    """Untimed calls of the same step until the time of a chunk of twenty stops changing
+    (two chunks in a row within 0.5 % of the one before).
+
+    After a load step the chip drops its clock within 2-3 ms and then raises it again over about
+    30 ms of continuous load (profiles/r03_launch_series.txt: the ingest launch goes 628 -> 754 ->
+    550 us and stays there for seconds); the driver's five warm-up steps end in the middle of that.
+    The timed region that follows measures the rate the chip sustains, and the line reports this
+    phase and the first window next to it.  Every rank runs the same number of chunks (they agree
+    with one all-reduce per chunk), so steps that gather stay matched."""
+    if not enabled:
+        return {"calls": 0}
+    prev, n, t_begin, first, calm = None, 0, time.perf_counter(), None, 0
+    for _ in range(max_chunks):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(chunk):
+            step()
+        sync()
+        ms = (time.perf_counter() - t0) * 1e3 / chunk
+        n += chunk
+        first = ms if first is None else first
+        calm = calm + 1 if prev is not None and abs(ms - prev) <= tol * prev else 0
+        done = calm >= 2
+        if dist is not None:
+            flag = torch.tensor([0 if done else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # go on while any rank still changes
+            done = not bool(flag.item())
+        prev = ms
+        if done:
+            break
+    return {"calls": n, "ms": round((time.perf_counter() - t_begin) * 1e3, 1),
+            "first_chunk_ms_per_step": round(first, 4), "last_chunk_ms_per_step": round(prev, 4)}
 
 
 def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
@@ -446,6 +485,27 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     elif do_gather:
         ctx.allgather_wait(-1)
     torch.cuda.synchronize()
+
+    def drain():
+        ctx.sync()
+        if sg:
+            sg.finish()
+        elif do_gather:
+            ctx.allgather_wait(-1)
+        torch.cuda.synchronize()
+
+    # the window right behind the warm-up steps, timed the same way, for the record (the chip's clock is
+    # still moving there); then untimed calls until it has settled; then the timed region proper
+    first_window_ms = None
+    if not args.no_settle:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        first_window_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    settled = settle_clock(step, drain, torch, dist, dev, not args.no_settle)
+    if sg and sg.times is not None:
+        sg.times.clear()
     ctx.profile_enable(True)
     if dist is not None:
         dist.barrier()
@@ -517,12 +577,16 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
             # which does not depend on the clock the chip held; else this run's time at the probed clock
             have = N_SIMD * (valu["grbm_gui_active"] / 8.0 if valu.get("grbm_gui_active") else
                              front_avg_ms * 1e-3 * valu["clock_ghz"] * 1e9)
-            roof_s = need / (N_SIMD * valu["clock_ghz"] * 1e9)  # launch time if the SIMDs never waited
+            # the clock this run held: the cycle count of a launch does not depend on it, its duration does
+            clock_ghz = (valu["grbm_gui_active"] / 8.0 / (front_avg_ms * 1e-3) / 1e9) if valu.get("grbm_gui_active") \
+                else valu["clock_ghz"]
+            roof_s = need / (N_SIMD * clock_ghz * 1e9)  # launch time if the SIMDs never waited
             roof["valu"] = {
                 "insts_per_sample": valu["insts_per_sample"],
                 "slow_per_sample": valu["slow_per_sample"], "fast_per_sample": valu["fast_per_sample"],
                 "issue_cycles_per_inst": {"slow": valu["issue_cycles_slow"], "fast": valu["issue_cycles_fast"]},
-                "clock_ghz": valu["clock_ghz"],
+                "clock_ghz": round(clock_ghz, 3),
+                "clock_ghz_of_counter_pass": valu["clock_ghz"],
                 "issue_util": round(need / have, 4),
                 "launch_ms_at_issue_roof": round(roof_s * 1e3, 4),
                 "hbm_frac_at_issue_roof": round(BYTES_PER_CHANNEL_SAMPLE * nch * S / roof_s / 1e9 / HBM_PEAK_GBS, 4),
@@ -533,7 +597,7 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
                 # kernel's mix, every instruction independent, issues at one rate whatever the class
                 # (probe rows front_mix_spread / front_mix_runs): the roof of the mixed stream
                 need_mx = valu["insts_per_sample"] * valu["issue_cycles_mixed"] * waves
-                roof_mx = need_mx / (N_SIMD * valu["clock_ghz"] * 1e9)
+                roof_mx = need_mx / (N_SIMD * clock_ghz * 1e9)
                 roof["valu"]["mixed_stream"] = {
                     "issue_cycles_per_inst": valu["issue_cycles_mixed"],
                     "issue_cycles_per_inst_fast_in_runs": valu.get("issue_cycles_mixed_runs"),
@@ -573,6 +637,11 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
                     world, ", RCCL all-gather of decimated I/Q each step, overlapped with the next step"
                     if do_gather else ""),
                 "parity_check": check,
+                "clock_settle": dict(settled, first_window_ms_per_step=None if first_window_ms is None else round(first_window_ms, 4),
+                                     what="untimed calls of the same step between the warm-up steps and the timed region, until "
+                                          "the time of twenty calls has changed by less than 0.5 % twice in a row: the chip lowers its clock right after "
+                                          "load arrives and takes about 30 ms of load to raise it again; first_window = the "
+                                          "--steps calls directly behind the warm-up, timed the same way"),
             },
             "roofline": roof,
         }
@@ -640,10 +709,24 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
     ev1 = torch.cuda.Event(enable_timing=True)
     ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
     torch.cuda.synchronize()  # torch filled iq / dac on its own stream
-    for _ in range(args.warmup):
+    def step():
         ctx.tx_process_dev(iq.data_ptr(), n_iq, dac.data_ptr())
-    ctx.sync()
-    torch.cuda.synchronize()
+
+    def drain():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    first_window_ms = None
+    if not args.no_settle:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        first_window_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    settled = settle_clock(step, drain, torch, dist, dev, not args.no_settle)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -674,8 +757,12 @@ def bench_tx(args, dev, local_rank, rank, world, dist):
             "data": "synthetic: uniform random 48 kHz I/Q, generated on device",
             "config": {"workload": "BASELINE config 4 shape: %d channels x %d I/Q pairs -> %d DAC words per channel "
                                    "per step (tx_ciccomp + tx_cic + tx_mixer + DAC_corrector)" % (nch, n_iq, S),
-                       "channels_per_gpu": nch, "parity_check": check},
-            "roofline": {"bound": "hbm", "kernel": "whole ddc_tx_process_dev call (ddc_tx_duc dominates)",
+                       "channels_per_gpu": nch, "parity_check": check,
+                       "clock_settle": dict(settled, first_window_ms_per_step=None if first_window_ms is None
+                                            else round(first_window_ms, 4))},
+            "roofline": {"bound": "valu-issue (vector-ALU instruction issue, profiles/r02_c_tx_sq_counters.txt; fraction "
+                                  "quoted against the HBM peak)",
+                         "kernel": "whole ddc_tx_process_dev call (ddc_tx_duc dominates)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "frac_of_step": round(bytes_per * nch * S / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),

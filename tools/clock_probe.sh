@@ -5,7 +5,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/clk_$tag
 mkdir -p $out
-timeout -s KILL 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-copy-rate --no-secondary "$@" > $out/run.log 2>&1 || { echo "probe failed"; tail -5 $out/run.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-check --no-copy-rate --no-secondary --no-settle "$@" > $out/run.log 2>&1 || { echo "probe failed"; tail -5 $out/run.log; exit 1; }
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]

@@ -9,7 +9,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 pass() {
     name=$1; shift
-    timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-copy-rate --no-secondary $BENCH_ARGS > $out/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/pmc_$name.log; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $out/pmc_$name -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-copy-rate --no-secondary --no-settle $BENCH_ARGS > $out/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -5 $out/pmc_$name.log; exit 1; }
     python3 tools/pmc_summary.py $out/pmc_$name >> $out/pmc_sq.txt
     rm -rf $out/pmc_$name
 }

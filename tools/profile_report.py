@@ -8,7 +8,7 @@ tag, out_path = sys.argv[1], sys.argv[2]
 d = "gpurun_out/" + tag
 rows = list(csv.DictReader(open(d + "/kernel_stats.csv")))
 out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (MI355X; default workload: 1024 channels x "
-       "2^20 samples, 3 warm-up + 20 timed steps + 1 parity-check call of 131072 samples)",
+       "2^20 samples: 3 warm-up + 20 first-window + the settle calls + 20 timed steps, and 1 parity-check call of 131072 samples)",
        "# library kernels only (ddc_synth_* generate the synthetic ADC rows before the timed region)",
        "%-28s %6s %14s %12s %10s %10s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns")]
 for r in rows:
@@ -24,6 +24,12 @@ for r in rows:
         c = int(r["Calls"])
         out.append("#   %s full-size average = %.1f us" % (n.replace("ddc::", ""),
             (float(r["TotalDurationNs"]) - float(r["MinNs"])) / (c - 1) / 1e3))
+try:
+    out.append("")
+    out.append("# the same trace split by the bench's phases (the timed region = the last 20 full-size launches):")
+    out.append(open(d + "/trace_phases.txt").read().rstrip())
+except OSError:
+    pass
 out.append("")
 out.append("# bench.py line of the same build (HIP events on the ctx stream):")
 out.append(open(d + "/bench.json").read().strip())
