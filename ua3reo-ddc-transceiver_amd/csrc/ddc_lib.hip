@@ -18,6 +18,7 @@
 
 #include "../../include/ua3reo_ddc.h"
 #include "ddc_rx_kernels.hip.h"
+#include "ddc_rx_mx_kernel.hip.h"
 #include "ddc_tx_kernels.hip.h"
 #include "ddc_audio_kernels.hip.h"
 #include <array>
@@ -49,6 +50,7 @@ struct ddc_ctx {
     uint32_t *d_phi = nullptr;   // tuning word << 10
     uint32_t *d_carry[2] = {nullptr, nullptr}; // [0] saved between calls, [1] the copy one call reads
     uint2 *d_nco_tab = nullptr;
+    uint4 *d_mx_tab = nullptr;   // byte planes of the window-moment weights (ddc_rx_front_mx)
     // work buffers, sized for cap_blk blocks of 512 samples per channel
     uint32_t cap_blk = 0;
     uint32_t last_blk = 0;
@@ -64,7 +66,7 @@ struct ddc_ctx {
     uint32_t *d_cnt = nullptr;            // arrival counters, zero between calls
     uint32_t *d_comp_tail = nullptr;      // last 256 compensator outputs of a call, on their way into the history
     size_t cnt_words = 0;
-    int rx_plan = 0;                      // 0: by shape; 1: always the separate kernels (ddc_debug_rx_plan)
+    int rx_plan = 0;                      // 0: by shape; 1: always the separate kernels; 2: by shape, vector-ALU ingest (ddc_debug_rx_plan)
     // history saved between calls (layout independent of the call size)
     unsigned long long *d_hist_mom = nullptr; // [ch][5][10]
     int16_t *d_hist_cic = nullptr;            // [ch][64][2]
@@ -299,7 +301,7 @@ void device_tables_mark_ready(int device)
 // calls whatever plan or shape the calls before had, because nothing else is ever put there.
 constexpr size_t kStaticCntBytes = 256u << 10;
 struct WorkLayout { bool fused; size_t mom, cic, comp, edge, tail, cnt_words, total; };
-bool plan_is_fused(int rx_plan, size_t n_blk) { return rx_plan == 0 && n_blk % ddc::kFrontThreads == 0; }
+bool plan_is_fused(int rx_plan, size_t n_blk) { return rx_plan != 1 && n_blk % ddc::kFrontThreads == 0; }
 WorkLayout work_layout(size_t nch, size_t n_blk, bool fused)
 {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -513,6 +515,13 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
             }
     }
     CREATE_TRY(hipMemcpyAsync(ctx->d_nco_tab, tab.data(), 2048 * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint8_t> mx(ddc::kMxTabBytes);
+    if (!ddc::build_mx_table(mx.data())) {
+        ctx->err = "a window-moment weight does not fit its byte planes";
+        return bail(-EFAULT);
+    }
+    CREATE_TRY(hipMalloc(&ctx->d_mx_tab, ddc::kMxTabBytes));
+    CREATE_TRY(hipMemcpyAsync(ctx->d_mx_tab, mx.data(), ddc::kMxTabBytes, hipMemcpyHostToDevice, ctx->stream));
     CONST_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_ciccomp_h), rx_ciccomp_h, sizeof rx_ciccomp_h, 0,
                                       hipMemcpyHostToDevice, ctx->stream));
     CONST_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ddc::c_rx_hilb_c), rx_hilb_c, sizeof rx_hilb_c, 0,
@@ -600,7 +609,7 @@ void ddc_destroy(ddc_ctx *ctx)
     void *ptrs[] = { ctx->d_acc, ctx->d_phi, ctx->d_carry[0], ctx->d_carry[1], ctx->d_nco_tab, ctx->d_mom,
                      ctx->d_cic, ctx->d_comp, ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, ctx->d_in,
                      ctx->d_out, ctx->d_tx_xs, ctx->d_fft_rows, ctx->d_wtf, ctx->d_adc_min, ctx->d_adc_max, ctx->d_audio, ctx->d_zoom, ctx->d_audio_tx, ctx->d_fft_work, ctx->d_fft_mag, ctx->d_stage[0], ctx->d_stage[1],
-                     ctx->d_stage[2], ctx->d_cicf, ctx->d_edge, ctx->d_cnt, ctx->d_comp_tail, ctx->d_audio_filt };
+                     ctx->d_stage[2], ctx->d_cicf, ctx->d_edge, ctx->d_cnt, ctx->d_comp_tail, ctx->d_audio_filt, ctx->d_mx_tab };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     ddc_tx_state_destroy(&ctx->tx);
@@ -759,8 +768,12 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
         fa.spec_iq = spec_iq; fa.voice_iq = voice_iq;
         fa.n_wg = (uint32_t)f.n_wg; fa.n_tiles = (uint32_t)f.n_tiles; fa.samples_lo = (uint32_t)samples;
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
-        ddc::ddc_rx_front_cic<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, total,
-                                                                                       ctx->d_phi, ctx->d_nco_tab, fa);
+        if (ctx->rx_plan == 2)
+            ddc::ddc_rx_front_cic<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, total,
+                                                                                           ctx->d_phi, ctx->d_nco_tab, fa);
+        else
+            ddc::ddc_rx_front_mx<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, ctx->d_phi,
+                                                                                          ctx->d_nco_tab, ctx->d_mx_tab, fa);
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
         ddc::ddc_rx_tail<<<nch * fa.n_tiles, 256, 0, st>>>(n_blk, fa);
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
@@ -869,7 +882,7 @@ int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_byt
 int ddc_debug_rx_plan(ddc_ctx *ctx, int plan)
 {
     if (!ctx) return -EINVAL;
-    if (plan != 0 && plan != 1) return fail(ctx, -EINVAL, "ddc_debug_rx_plan: plan is 0 or 1");
+    if (plan < 0 || plan > 2) return fail(ctx, -EINVAL, "ddc_debug_rx_plan: plan is 0, 1 or 2");
     ctx->rx_plan = plan;
     return 0;
 }
