@@ -174,7 +174,9 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     __shared__ unsigned long long tfix[4][10];
     static_assert(4 * kMxStage >= 10 * kFrontThreads * 8, "the staging buffer also holds the moments of 256 windows");
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, wave_base = tid & ~63u;
+    // wv is the same in every lane of a wave: through readfirstlane, so that what depends on it alone
+    // (the wave's rows, its staging buffer) stays in scalar registers
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = __builtin_amdgcn_readfirstlane(tid >> 6), wave_base = wv * 64u;
     const uint32_t n = lane & 15u, g = lane >> 4;
 
     // the coarse NCO table and the weight rows: straight into LDS, waited for with the first lines
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     char *wstage = stage + wv * kMxStage;
 #define DDC_MX_ISSUE(it_)                                                                                   \
     do {                                                                                                    \
-        const uint32_t base_ = ((it_) >> 1) * (16u * kBlkBytes) + ((it_) & 1u) * 384u;                      \
+        const uint8_t *half_ = wave_rows + (((it_) >> 1) * (16u * kBlkBytes) + ((it_) & 1u) * 384u);        \
         _Pragma("unroll") for (int i_ = 0; i_ < kMxDmas; i_++)                                              \
             if (doff[i_] != 0xFFFFFFFFu)                                                                    \
-                lds_dma16(wave_rows + (base_ + doff[i_]), reinterpret_cast<uint4 *>(wstage + 1024 * i_));   \
+                lds_dma16(half_ + doff[i_], reinterpret_cast<uint4 *>(wstage + 1024 * i_));                 \
     } while (0)
     DDC_MX_ISSUE(0u);
 
@@ -213,8 +215,9 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     const unsigned long long skip48 = (unsigned long long)(48u * phi32) | ((unsigned long long)(48u * phi32) << 32);
     unsigned long long accp = 0;
 
-    v4i aih = {0, 0, 0, 0}, ail = {0, 0, 0, 0}, aqh = {0, 0, 0, 0}, aql = {0, 0, 0, 0};
-    uint32_t Z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // planes of the five samples before a window, as the upper two dwords of a second operand each
+    // (the lower two meet zero weights and may hold anything)
+    v4i zih = {0, 0, 0, 0}, zil = {0, 0, 0, 0}, zqh = {0, 0, 0, 0}, zql = {0, 0, 0, 0};
     MxPart s0{}, s1{}, s2{}, s3{};
     unsigned last_i[3] = {0, 0, 0}, last_q[3] = {0, 0, 0};
 
@@ -225,20 +228,19 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     __syncthreads(); // the tables of all four waves are in place
 
 #pragma unroll 1
-    for (uint32_t it = 0; it < 8; it++) {
-        const uint32_t p = it >> 1, h = it & 1u;
-        if (it) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's lines of the half have landed
-        if (!h) {
+    for (uint32_t p = 0; p < 4; p++) {
+        {
             const uint32_t b = kw * kFrontThreads + wv * 64u + p * 16u + n;
             const uint32_t acc32 = (acc_ch + (b * (uint32_t)kBlk + 16u * g) * phi_in) >> 2;
             accp = (unsigned long long)acc32 | ((unsigned long long)(acc32 + phi32) << 32);
-            aih = v4i{0, 0, 0, 0}; ail = v4i{0, 0, 0, 0}; aqh = v4i{0, 0, 0, 0}; aql = v4i{0, 0, 0, 0};
         }
-        const char *wr = wrow + h * 4096u;
+        v4i aih, ail, aqh, aql;
         int hi_i[4], lo_i[4], hi_q[4], lo_q[4];
         uint2 nx0 = make_uint2(0, 0), nx1 = make_uint2(0, 0), nx2 = make_uint2(0, 0);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int hc = 0; hc < 8; hc++) {
+            const int h = hc >> 2, c = hc & 3;
+            if (c == 0 && (h || p)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's lines of the half have landed
             uint2 v0, v1, v2;
             if (c < 3) {
                 v0 = *reinterpret_cast<const uint2 *>(rd + 96 * c);
@@ -252,9 +254,10 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
                 nx1 = *reinterpret_cast<const uint2 *>(rd + 96 * 3 + 8);
                 nx2 = *reinterpret_cast<const uint2 *>(rd + 96 * 3 + 16);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (it < 7) DDC_MX_ISSUE(it + 1u);
+                if (h == 0) DDC_MX_ISSUE(2u * p + 1u);
+                else if (p < 3) DDC_MX_ISSUE(2u * p + 2u);
             }
-            const uint4 wa = *reinterpret_cast<const uint4 *>(wr + 1024 * c);
+            const uint4 wa = *reinterpret_cast<const uint4 *>(wrow + 1024 * hc);
             const v4i A = { (int)wa.x, (int)wa.y, (int)wa.z, (int)wa.w };
             unsigned pi[8], pq[8];
             mx_group8(tab, v0.x, v0.y, v1.x, accp, phi2, pi, pq);
@@ -265,39 +268,40 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
                 mx_planes(pi[2 * m], pi[2 * m + 1], hi_i[m], lo_i[m]);
                 mx_planes(pq[2 * m], pq[2 * m + 1], hi_q[m], lo_q[m]);
             }
-            aih = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{hi_i[0], hi_i[1], hi_i[2], hi_i[3]}, aih, 0, 0, 0);
-            ail = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{lo_i[0], lo_i[1], lo_i[2], lo_i[3]}, ail, 0, 0, 0);
-            aqh = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{hi_q[0], hi_q[1], hi_q[2], hi_q[3]}, aqh, 0, 0, 0);
-            aql = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{lo_q[0], lo_q[1], lo_q[2], lo_q[3]}, aql, 0, 0, 0);
-            if (c == 3) {
+            const v4i zero = {0, 0, 0, 0};
+            aih = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{hi_i[0], hi_i[1], hi_i[2], hi_i[3]}, hc ? aih : zero, 0, 0, 0);
+            ail = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{lo_i[0], lo_i[1], lo_i[2], lo_i[3]}, hc ? ail : zero, 0, 0, 0);
+            aqh = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{hi_q[0], hi_q[1], hi_q[2], hi_q[3]}, hc ? aqh : zero, 0, 0, 0);
+            aql = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, v4i{lo_q[0], lo_q[1], lo_q[2], lo_q[3]}, hc ? aql : zero, 0, 0, 0);
+            if (hc == 7) {
                 last_i[0] = pi[5]; last_i[1] = pi[6]; last_i[2] = pi[7];
                 last_q[0] = pq[5]; last_q[1] = pq[6]; last_q[2] = pq[7];
             }
         }
-        if (h) {
-            // the block's last five samples open the next window: their planes (K slots 11..15 = the
-            // upper two dwords) go one lane up; lane 0 of a row keeps what the pass before left it
-            const uint32_t P[8] = { (uint32_t)hi_i[2], (uint32_t)hi_i[3], (uint32_t)lo_i[2], (uint32_t)lo_i[3],
-                                    (uint32_t)hi_q[2], (uint32_t)hi_q[3], (uint32_t)lo_q[2], (uint32_t)lo_q[3] };
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                Z[j] = (uint32_t)__builtin_amdgcn_update_dpp((int)Z[j], (int)P[j], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-            const uint4 wt = *reinterpret_cast<const uint4 *>(wrow + 8 * 1024);
-            const v4i At = { (int)wt.x, (int)wt.y, (int)wt.z, (int)wt.w };
-            aih = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, v4i{0, 0, (int)Z[0], (int)Z[1]}, aih, 0, 0, 0);
-            ail = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, v4i{0, 0, (int)Z[2], (int)Z[3]}, ail, 0, 0, 0);
-            aqh = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, v4i{0, 0, (int)Z[4], (int)Z[5]}, aqh, 0, 0, 0);
-            aql = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, v4i{0, 0, (int)Z[6], (int)Z[7]}, aql, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                Z[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P[j], 0x121 /* row_ror:1 */, 0xf, 0xf, true);
-            MxPart part;
-            mx_recombine(aih, ail, aqh, aql, lane, part);
-            if (p == 0) s0 = part;
-            else if (p == 1) s1 = part;
-            else if (p == 2) s2 = part;
-            else s3 = part;
-        }
+        // The block's last five samples open the next window: their planes (K slots 11..15 = the
+        // upper two dwords) go one lane up; lane 0 of a row keeps what the pass before left it.
+#define DDC_MX_UP(z_, src_)                                                                                            \
+        z_[2] = __builtin_amdgcn_update_dpp(z_[2], src_[2], 0x111 /* row_shr:1 */, 0xf, 0xf, false);                   \
+        z_[3] = __builtin_amdgcn_update_dpp(z_[3], src_[3], 0x111, 0xf, 0xf, false)
+#define DDC_MX_KEEP(z_, src_)                                                                                          \
+        z_[2] = __builtin_amdgcn_update_dpp(0, src_[2], 0x121 /* row_ror:1 */, 0xf, 0xf, true);                        \
+        z_[3] = __builtin_amdgcn_update_dpp(0, src_[3], 0x121, 0xf, 0xf, true)
+        DDC_MX_UP(zih, hi_i); DDC_MX_UP(zil, lo_i); DDC_MX_UP(zqh, hi_q); DDC_MX_UP(zql, lo_q);
+        const uint4 wt = *reinterpret_cast<const uint4 *>(wrow + 8 * 1024);
+        const v4i At = { (int)wt.x, (int)wt.y, (int)wt.z, (int)wt.w };
+        aih = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, zih, aih, 0, 0, 0);
+        ail = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, zil, ail, 0, 0, 0);
+        aqh = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, zqh, aqh, 0, 0, 0);
+        aql = __builtin_amdgcn_mfma_i32_16x16x64_i8(At, zql, aql, 0, 0, 0);
+        DDC_MX_KEEP(zih, hi_i); DDC_MX_KEEP(zil, lo_i); DDC_MX_KEEP(zqh, hi_q); DDC_MX_KEEP(zql, lo_q);
+#undef DDC_MX_UP
+#undef DDC_MX_KEEP
+        MxPart part;
+        mx_recombine(aih, ail, aqh, aql, lane, part);
+        if (p == 0) s0 = part;
+        else if (p == 1) s1 = part;
+        else if (p == 2) s2 = part;
+        else s3 = part;
     }
 #undef DDC_MX_ISSUE
 
@@ -311,8 +315,9 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     }
     // lane 0 of row 3 now holds the planes of the wave's last five samples
     if (lane == 48) {
+        const int zs[8] = { zih[2], zih[3], zil[2], zil[3], zqh[2], zqh[3], zql[2], zql[3] };
 #pragma unroll
-        for (int j = 0; j < 8; j++) xch[wv][j] = Z[j];
+        for (int j = 0; j < 8; j++) xch[wv][j] = (uint32_t)zs[j];
     }
     __syncthreads();
     if (wv == 0) {
