@@ -34,7 +34,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 BYTES_PER_CHANNEL_SAMPLE = 1.5 + 8.0 / 1024.0  # packed ADC read + SPEC/VOICE int16 I/Q written
 FS_ADC = 49152000
 N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
-FRONT_SOURCE = os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_rx_kernels.hip.h")
+# the ingest kernel of the default call plan and the functions it shares with the other kernels
+FRONT_SOURCES = [os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", f)
+                 for f in ("ddc_rx_kernels.hip.h", "ddc_rx_mx_kernel.hip.h")]
 
 
 class _StdoutToStderr:
@@ -73,9 +75,10 @@ def parse_args(argv=None):
     ap.add_argument("--shared-stream", action="store_true",
                     help="one ADC stream fanned out to every channel (row pitch 0) instead of one stream per channel; "
                          "reported apart from the headline: the ADC bytes then come from L2, not HBM")
-    ap.add_argument("--rx-plan", choices=["auto", "split"], default="auto",
-                    help="auto: the library picks the RX call plan by size (one kernel for the bench shapes); "
-                         "split: the separate kernels, for A/B timing on one box")
+    ap.add_argument("--rx-plan", choices=["auto", "split", "valu"], default="auto",
+                    help="auto: the library picks the RX call plan by size (two kernels for the bench shapes, the ingest "
+                         "kernel with the window moments on the matrix cores); valu: the same plan with the vector-ALU "
+                         "ingest kernel; split: the six separate kernels; for A/B timing on one box")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU)")
     ap.add_argument("--gather", choices=["library", "torch"], default="library",
@@ -118,8 +121,11 @@ def launch_ranks(args, argv):
 
 
 def source_hash():
-    with open(FRONT_SOURCE, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for path in FRONT_SOURCES:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def load_profile(name, nch, samples):
@@ -364,6 +370,8 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
     ctx.tune_many(phis)
     if args.rx_plan == "split":
         ctx.debug_rx_plan(1)
+    elif args.rx_plan == "valu":
+        ctx.debug_rx_plan(2)
     fft_params = dict(mode="USB", fft_averaging=4)
     if with_fft:
         ctx.audio_configure(ua3reo_ddc.audio_params(**fft_params))
@@ -538,11 +546,12 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
         units = float(world) * nch * S * args.steps  # channel-samples ingested by the whole job
         value = units / dt / 1e6
         front_avg_ms = front_ms / max(1, ncalls)
-        two_kernels = args.rx_plan == "auto" and (S // 512) % 256 == 0
-        kernel_name = "ddc_rx_front_cic" if two_kernels else "ddc_rx_front"
+        two_kernels = args.rx_plan != "split" and (S // 512) % 256 == 0
+        kernel_name = ("ddc_rx_front_mx" if args.rx_plan == "auto" else "ddc_rx_front_cic") if two_kernels else "ddc_rx_front"
         achieved = BYTES_PER_CHANNEL_SAMPLE * nch * S / (front_avg_ms * 1e-3) / 1e9
-        traffic = None if shared else load_profile("traffic.json", nch, S)
-        valu = None if shared else load_profile("valu.json", nch, S)
+        # the committed counter passes are of the default plan's ingest kernel
+        traffic = None if shared or args.rx_plan != "auto" else load_profile("traffic.json", nch, S)
+        valu = None if shared or args.rx_plan != "auto" else load_profile("valu.json", nch, S)
         step_ms = dt / args.steps * 1e3
         roof = {
             # the fraction is quoted against the HBM peak; what holds the kernel back is named below

@@ -103,3 +103,66 @@ def test_generated_header_is_current(tmp_path):
     cur = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        "ua3reo-ddc-transceiver_amd", "csrc", "ddc_cic_consts.h")
     assert open(cur).read() == p.read_text()
+
+
+def test_moment_weight_planes_of_the_matrix_ingest_kernel():
+    """ddc_rx_front_mx multiplies byte planes: the table compiled into the library
+    (ddc_debug_table "rx_moment_weights": [step][lane 16 g + row][16 K slots]) recombines to
+    the binomial weights C(d + e, e) of every sample of a window, its digits are signed bytes,
+    the five newest samples of a block carry no weight in the block's own rows and the ninth
+    row holds them as the oldest samples (d = 511..507) of the next window.  A block of random
+    mixer outputs pushed through the planes the way the kernel does it (high byte and the seven
+    bits below of 2 x, 32-bit sums per plane, 128 hi + lo recombined with powers of 256) gives
+    the moments of cm.block_moments."""
+    import ua3reo_ddc
+    tab = ua3reo_ddc.debug_table("rx_moment_weights", np.int8).reshape(9, 4, 16, 16).astype(np.int64)  # [step][g][row][j]
+    rows = {}
+    r = 0
+    for e in (4, 3, 2, 1, 0):
+        for p in range(e + 1):
+            rows[(e, p)] = r
+            r += 1
+    assert r == 15 and not tab[:, :, 15, :].any()
+
+    def weight(step, g, j, e):
+        return sum(int(tab[step, g, rows[(e, p)], j]) << (8 * p) for p in range(e + 1))
+
+    for c in range(8):
+        for g in range(4):
+            for j in range(16):
+                s = 64 * c + 16 * g + j
+                for e in range(5):
+                    want = cm.binom_poly(506 - s + e, e) if s <= 506 else 0
+                    assert weight(c, g, j, e) == want, (s, e)
+    for g in range(4):
+        for j in range(16):
+            for e in range(5):
+                want = cm.binom_poly(511 - (j - 11) + e, e) if (g == 3 and j >= 11) else 0
+                assert weight(8, g, j, e) == want, (g, j, e)
+    # the kernel's arithmetic on one window
+    rng = np.random.default_rng(7)
+    x_prev5 = [int(v) for v in rng.integers(-16384, 16384, 5)]
+    x_blk = [int(v) for v in rng.integers(-16384, 16384, 512)]
+    x_blk[3], x_blk[100], x_prev5[0] = -16384, 16383, -16384
+    want = cm.block_moments([2 * v for v in x_prev5], [2 * v for v in x_blk])
+
+    def planes(x):  # 2 x = 256 hi + 2 lo7, hi a signed byte
+        x2 = 2 * x
+        lo = x2 & 255
+        return (x2 - lo) // 256, lo >> 1
+
+    acc = np.zeros((16, 2), np.int64)
+    for c in range(8):
+        for g in range(4):
+            for j in range(16):
+                hi, lo = planes(x_blk[64 * c + 16 * g + j])
+                acc[:, 0] += tab[c, g, :, j] * hi
+                acc[:, 1] += tab[c, g, :, j] * lo
+    for j in range(11, 16):
+        hi, lo = planes(x_prev5[j - 11])
+        acc[:, 0] += tab[8, 3, :, j] * hi
+        acc[:, 1] += tab[8, 3, :, j] * lo
+    assert np.abs(acc).max() < (1 << 24)
+    for e in range(5):
+        got = sum((2 * (128 * int(acc[rows[(e, p)], 0]) + int(acc[rows[(e, p)], 1]))) << (8 * p) for p in range(e + 1))
+        assert got & cm.MASK64 == want[e] & cm.MASK64, e

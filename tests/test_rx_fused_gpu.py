@@ -3,7 +3,9 @@
 and the state hand-over) against the oracle and against the six-kernel plan of the same
 library: every output bit-exact, for single short tiles, several tiles with a partial last
 one, calls of both plans alternating on one stream of samples, many channels at once, and
-the raw rx_cic tap."""
+the raw rx_cic tap.  The plan has two ingest kernels: ddc_rx_front_mx (window moments on the
+matrix cores, what the library picks: plan 0) and ddc_rx_front_cic (vector ALU only: plan 2
+of ddc_debug_rx_plan); both are held to the same results."""
 import numpy as np
 import pytest
 
@@ -23,8 +25,9 @@ def rows_of(ddc, chans):
     return np.stack([ddc.pack_adc12(x) for x in chans])
 
 
+@pytest.mark.parametrize("ingest", [0, 2])
 @pytest.mark.parametrize("n_wg", [1, 2, 7, 8, 9, 17])
-def test_two_kernel_call_equals_oracle_and_split_plan(ddc, orc, n_wg):
+def test_two_kernel_call_equals_oracle_and_split_plan(ddc, orc, n_wg, ingest):
     """n_wg workgroups per channel: 1 / 2 / 7 (a short tile), 8 (one full tile), 9 and 17
     (tiles that reach back into the previous one, the last tile partial)."""
     n = n_wg * BLK
@@ -36,6 +39,7 @@ def test_two_kernel_call_equals_oracle_and_split_plan(ddc, orc, n_wg):
     rows = rows_of(ddc, chans)
     d = ddc.Ddc(nch)
     d.tune_many(phis)
+    d.debug_rx_plan(ingest)
     spec, voice = d.rx_process(rows, n)
     cic = d.rx_read_cic(n)
     e = ddc.Ddc(nch)
@@ -58,6 +62,38 @@ def test_two_kernel_call_equals_oracle_and_split_plan(ddc, orc, n_wg):
         assert d.rx_get_phase(c) == e.rx_get_phase(c) == (phis[c] * (n + BLK)) & 0x3FFFFF
     d.close()
     e.close()
+
+
+@pytest.mark.parametrize("ingest", [0, 2])
+def test_rails_and_the_mixer_product_that_wraps(ddc, orc, ingest):
+    """-2048 * -2048 = 2^22 is the one mixer product that leaves 23 bits (FPGA/rx_mixer_shift.v:9 keeps
+    bits 22..8): rows held at the negative rail with tuning words that put the NCO on -2048 (sine at
+    three quarters of a turn, cosine at half a turn) every few samples, the positive rail, and rows
+    that flip between the rails, over two calls."""
+    n = 2 * BLK
+    phis = [1 << 20, 3 << 20, 1 << 21, 1, 4194303, 605867, (1 << 20) + 1, 2796203]
+    nch = len(phis)
+    rng = np.random.default_rng(77)
+    chans = []
+    for c in range(nch):
+        x = np.full(2 * n, -2048, np.int16)
+        if c % 4 == 1:
+            x[:] = 2047
+        elif c % 4 == 2:
+            x[rng.integers(0, 2, 2 * n) == 1] = 2047
+        elif c % 4 == 3:
+            x[::7] = rng.integers(-2048, 2048, len(x[::7]))
+        chans.append(x)
+    d = ddc.Ddc(nch)
+    d.tune_many(phis)
+    d.debug_rx_plan(ingest)
+    outs = [d.rx_process(rows_of(ddc, [x[k * n:(k + 1) * n] for x in chans]), n) for k in range(2)]
+    d.close()
+    spec = np.concatenate([o[0] for o in outs], axis=1)
+    voice = np.concatenate([o[1] for o in outs], axis=1)
+    for c in range(nch):
+        ws, wv = orc.RxChain(phis[c]).run(chans[c])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
 
 
 @pytest.mark.parametrize("sizes", [[BLK, 1024, 2 * BLK, 3072, BLK], [9 * BLK, BLK, 1024 * 5, 8 * BLK],

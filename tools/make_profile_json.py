@@ -2,14 +2,14 @@
 """Turns the PMC summaries of one measurement round into the two small JSON files
 bench.py replays next to its live timing (it cannot read counters from inside a run):
 
-  profiles/traffic.json  HBM-side bytes per ddc_rx_front_cic launch (2 x FETCH_SIZE + WRITE_SIZE,
+  profiles/traffic.json  HBM-side bytes per ddc_rx_front_mx launch (2 x FETCH_SIZE + WRITE_SIZE,
                          KiB -> bytes; gfx950 tallies 128-byte fills at 64 bytes)
   profiles/valu.json     vector instructions per ADC sample (SQ_INSTS_VALU), split into the two
                          issue classes the probe (tools/probe/valu_issue.hip) found, with the
                          probe's cycles per wave-instruction per SIMD and the clock of the pass
 
 Both carry the hash of the kernel source they were measured on and the commit that holds it;
-bench.py ignores them once csrc/ddc_rx_kernels.hip.h has changed.  The tool refuses to write while
+bench.py ignores them once csrc/ddc_rx_kernels.hip.h or csrc/ddc_rx_mx_kernel.hip.h has changed.  The tool refuses to write while
 the kernel sources in the tree differ from HEAD: a counter pass is only worth recording against a
 source that is in the history.
 
@@ -24,8 +24,9 @@ import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_rx_kernels.hip.h")
-KERNEL = "ddc::ddc_rx_front_cic"
+SRCS = [os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", f) for f in ("ddc_rx_kernels.hip.h", "ddc_rx_mx_kernel.hip.h")]
+KERNEL = "ddc::ddc_rx_front_mx"
+LOOP_TRIPS = 4.0  # the sample loop of ddc_rx_front_mx runs once per pass of 16 windows
 # issue classes (profiles/r02_valu_issue_probe.txt): ~2.1 cycles per wave-instruction per SIMD
 FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32", "v_or_b32",
         "v_xor_b32", "v_mov_b32", "v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32", "v_mul_f32", "v_add_f32",
@@ -49,12 +50,13 @@ def medians(path, kernel):
 
 
 def static_mix():
-    """Fractions (slow, fast) of the vector instructions of ddc_rx_front_cic, blocks of the sample loop
-    weighted by its 16 trips, from the compiler's assembly of the source in the tree."""
+    """Fractions (slow, fast) of the vector instructions of ddc_rx_front_mx (matrix instructions left
+    out), blocks of the sample loop weighted by its trips, from the compiler's assembly of the source in
+    the tree."""
     asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-",
                           os.path.join(ROOT, "ua3reo-ddc-transceiver_amd", "csrc", "ddc_lib.hip")],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
-    i = asm.index("\n_ZN3ddc16ddc_rx_front_cicE")
+    i = asm.index("\n_ZN3ddc15ddc_rx_front_mxE")
     body = asm[i:asm.index("s_endpgm", i)].split("\n")
     # the sample loop is the loop with the most instructions
     loops, cur = {}, None
@@ -77,9 +79,9 @@ def static_mix():
     slow = fast = 0.0
     for ln, lp in zip(body, weight_of_line):
         m = re.match(r"^\s+(v_[a-z0-9_]+?)(_e32|_e64|_sdwa|_dpp)?\s", ln)
-        if not m:
+        if not m or m.group(1).startswith("v_mfma"):
             continue
-        w = 16.0 if lp == main else 1.0
+        w = LOOP_TRIPS if lp == main else 1.0
         name, suffix = m.group(1), m.group(2)
         if name in FAST and suffix not in ("_sdwa", "_dpp"):
             fast += w
@@ -97,14 +99,17 @@ def main():
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--source", default="tools/pmc_sq.sh / tools/gpu_measure.sh")
     a = ap.parse_args()
-    sha = hashlib.sha256(open(SRC, "rb").read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for path in SRCS:
+        h.update(open(path, "rb").read())
+    sha = h.hexdigest()[:16]
     git = lambda *args: subprocess.run(["git", "-C", ROOT] + list(args), stdout=subprocess.PIPE, check=True).stdout.decode().strip()
     dirty = git("status", "--porcelain", "--", "ua3reo-ddc-transceiver_amd/csrc", "include", "bench.py")
     if dirty:
         raise SystemExit("make_profile_json: kernel sources / bench.py differ from HEAD, commit them first:\n" + dirty)
     commit = git("rev-parse", "--short", "HEAD")
-    blob = git("rev-parse", "HEAD:ua3reo-ddc-transceiver_amd/csrc/ddc_rx_kernels.hip.h")
-    common = {"kernel": "ddc_rx_front_cic", "channels": a.channels, "samples": a.samples, "kernel_source_sha256_16": sha,
+    blob = " ".join(git("rev-parse", "HEAD:ua3reo-ddc-transceiver_amd/csrc/" + os.path.basename(path)) for path in SRCS)
+    common = {"kernel": "ddc_rx_front_mx", "channels": a.channels, "samples": a.samples, "kernel_source_sha256_16": sha,
               "commit": commit, "kernel_source_git_blob": blob}
     if a.traffic:
         m = medians(a.traffic, KERNEL)
@@ -119,7 +124,7 @@ def main():
         per_sample = m["SQ_INSTS_VALU"] * 64.0 / (a.channels * a.samples)
         fs, ff, loop_n = static_mix()
         v = dict(common, source=a.source + " (rocprofv3 --pmc SQ_INSTS_VALU ...; class split from the compiler's assembly, "
-                 "sample loop of %d vector instructions per 32 samples weighted by its 16 trips; issue cycles from "
+                 "sample loop of %d vector instructions per 128 samples weighted by its 4 trips; issue cycles from "
                  "tools/probe/valu_issue.hip, profiles/r02_valu_issue_probe.txt)" % loop_n,
                  sq_insts_valu=m["SQ_INSTS_VALU"], insts_per_sample=round(per_sample, 3),
                  slow_per_sample=round(per_sample * fs, 3), fast_per_sample=round(per_sample * ff, 3),

@@ -2012,6 +2012,7 @@ int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
     if (!name || !bytes) return -EINVAL;
     std::vector<uint2> nco;
     std::vector<int16_t> fine;
+    std::vector<uint8_t> mx;
     const void *src = nullptr;
     size_t n = 0;
     const std::string k(name);
@@ -2044,6 +2045,12 @@ int ddc_debug_table(const char *name, void *out, size_t cap, size_t *bytes)
         for (uint32_t f = 0; f < 2048; f++) fine[f] = (int16_t)(nco_fine_pair_host(f) & 0xFFFFu);
         src = fine.data();
         n = fine.size() * sizeof(int16_t);
+    }
+    if (k == "rx_moment_weights") {    // byte planes of the window-moment weights as ddc_rx_front_mx multiplies them
+        mx.resize(ddc::kMxTabBytes);
+        if (!ddc::build_mx_table(mx.data())) return fail(nullptr, -EFAULT, "a window-moment weight does not fit its byte planes");
+        src = mx.data();
+        n = mx.size();
     }
     if (!src) return fail(nullptr, -ENOENT, "no such table: " + k);
     *bytes = n;
