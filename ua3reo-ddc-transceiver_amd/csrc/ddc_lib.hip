@@ -772,8 +772,12 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
             ddc::ddc_rx_front_cic<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, total,
                                                                                            ctx->d_phi, ctx->d_nco_tab, fa);
         else
-            ddc::ddc_rx_front_mx<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, ctx->d_phi,
-                                                                                          ctx->d_nco_tab, ctx->d_mx_tab, fa);
+        {
+            // x: the channel's workgroups, (y, z): the channel
+            const uint32_t gy = std::min<uint32_t>(nch, 32768u), gz = (nch + gy - 1) / gy;
+            ddc::ddc_rx_front_mx<<<dim3(fa.n_wg, gy, gz), ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, nch, ctx->d_phi,
+                                                                                     ctx->d_nco_tab, ctx->d_mx_tab, fa);
+        }
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[1], st));
         ddc::ddc_rx_tail<<<nch * fa.n_tiles, 256, 0, st>>>(n_blk, fa);
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));

@@ -87,8 +87,9 @@ inline bool build_mx_table(uint8_t *tab /* kMxTabBytes */)
 }
 
 // eight samples: NCO, mixer, packed pairs {2 x_even | 2 x_odd << 16} per branch
+// (phi2_last: what the phase pair advances by behind the last two samples)
 __device__ __forceinline__ void mx_group8(const uint2 *tab, uint32_t d0, uint32_t d1, uint32_t d2,
-                                          unsigned long long &accp, unsigned long long phi2,
+                                          unsigned long long &accp, unsigned long long phi2, unsigned long long phi2_last,
                                           unsigned *pi, unsigned *pq)
 {
     int a[8];
@@ -100,7 +101,7 @@ __device__ __forceinline__ void mx_group8(const uint2 *tab, uint32_t d0, uint32_
     for (int k = 0; k < 4; k++) {
         nco_fetch(tab, (uint32_t)p, e[2 * k], w[2 * k]);
         nco_fetch(tab, (uint32_t)(p >> 32), e[2 * k + 1], w[2 * k + 1]);
-        p = pair_add(p, phi2);
+        p = pair_add(p, k == 3 ? phi2_last : phi2);
     }
     accp = p;
 #pragma unroll
@@ -164,7 +165,7 @@ __device__ __forceinline__ void mx_recombine(const v4i &ih, const v4i &il, const
 }
 
 __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
-    const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, const uint32_t *__restrict__ phi32v,
+    const uint8_t *__restrict__ adc, size_t row_bytes, uint32_t n_blk, uint32_t n_ch, const uint32_t *__restrict__ phi32v,
     const uint2 *__restrict__ nco_tab, const uint4 *__restrict__ mx_tab, const RxFused fa)
 {
     __shared__ uint2 tab[2048];
@@ -179,6 +180,9 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = __builtin_amdgcn_readfirstlane(tid >> 6), wave_base = wv * 64u;
     const uint32_t n = lane & 15u, g = lane >> 4;
 
+    // grid: x = workgroup within the channel's row, (y, z) = channel: no division, everything scalar
+    const uint32_t ch = blockIdx.z * gridDim.y + blockIdx.y, kw = blockIdx.x;
+    if (ch >= n_ch) return;
     // the coarse NCO table and the weight rows: straight into LDS, waited for with the first lines
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -189,7 +193,6 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
         lds_dma16(reinterpret_cast<const uint8_t *>(mx_tab) + (i * kFrontThreads + tid) * 16u, wtab + i * kFrontThreads + wave_base);
     if (wv == 0) lds_dma16(reinterpret_cast<const uint8_t *>(mx_tab) + (2 * kFrontThreads + tid) * 16u, wtab + 2 * kFrontThreads);
 
-    const uint32_t ch = blockIdx.x / fa.n_wg, kw = blockIdx.x - ch * fa.n_wg;
     // the 64 windows of the wave lie one behind the other in the channel's row
     const uint8_t *wave_rows = adc + (size_t)ch * row_bytes + ((size_t)kw * kFrontThreads + wv * 64u) * kBlkBytes;
 
@@ -203,7 +206,12 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     char *wstage = stage + wv * kMxStage;
 #define DDC_MX_ISSUE(it_)                                                                                   \
     do {                                                                                                    \
-        const uint8_t *half_ = wave_rows + (((it_) >> 1) * (16u * kBlkBytes) + ((it_) & 1u) * 384u);        \
+        /* the same address in every lane: through readfirstlane, so that one scalar base serves the loads */ \
+        const uint64_t ha_ = (uint64_t)(wave_rows + (((it_) >> 1) * (16u * kBlkBytes) + ((it_) & 1u) * 384u)); \
+        /* (the builtin returns int: without the casts the low half would be sign-extended over the high) */  \
+        const uint32_t hlo_ = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ha_);                      \
+        const uint32_t hhi_ = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ha_ >> 32));              \
+        const uint8_t *half_ = reinterpret_cast<const uint8_t *>(((uint64_t)hhi_ << 32) | (uint64_t)hlo_);  \
         _Pragma("unroll") for (int i_ = 0; i_ < kMxDmas; i_++)                                              \
             if (doff[i_] != 0xFFFFFFFFu)                                                                    \
                 lds_dma16(half_ + doff[i_], reinterpret_cast<uint4 *>(wstage + 1024 * i_));                 \
@@ -212,7 +220,8 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
 
     const uint32_t phi_in = phi32v[ch], phi32 = phi_in >> 2, acc_ch = fa.acc0[ch];
     const unsigned long long phi2 = (unsigned long long)(2u * phi32) | ((unsigned long long)(2u * phi32) << 32);
-    const unsigned long long skip48 = (unsigned long long)(48u * phi32) | ((unsigned long long)(48u * phi32) << 32);
+    // behind the 16 samples of a step a lane skips the 48 that the other three lane groups mix
+    const unsigned long long phi50 = (unsigned long long)(50u * phi32) | ((unsigned long long)(50u * phi32) << 32);
     unsigned long long accp = 0;
 
     // planes of the five samples before a window, as the upper two dwords of a second operand each
@@ -260,9 +269,8 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
             const uint4 wa = *reinterpret_cast<const uint4 *>(wrow + 1024 * hc);
             const v4i A = { (int)wa.x, (int)wa.y, (int)wa.z, (int)wa.w };
             unsigned pi[8], pq[8];
-            mx_group8(tab, v0.x, v0.y, v1.x, accp, phi2, pi, pq);
-            mx_group8(tab, v1.y, v2.x, v2.y, accp, phi2, pi + 4, pq + 4);
-            accp = pair_add(accp, skip48);
+            mx_group8(tab, v0.x, v0.y, v1.x, accp, phi2, phi2, pi, pq);
+            mx_group8(tab, v1.y, v2.x, v2.y, accp, phi2, phi50, pi + 4, pq + 4);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 mx_planes(pi[2 * m], pi[2 * m + 1], hi_i[m], lo_i[m]);
