@@ -232,3 +232,27 @@ def test_state_blob_travels_between_the_two_plans(ddc, orc):
         assert np.array_equal(s2[ch], ws[2 * nf:]) and np.array_equal(v2[ch], wv[2 * nf:])
     for d_ in (a, b, c):
         d_.close()
+
+
+def test_more_channels_than_one_grid_dimension_holds(ddc, orc):
+    """40000 receivers on one ADC row: ddc_rx_front_mx takes the channel from the grid's y and z
+    (y holds at most 32768), so channels on both sides of that seam against the oracle, and every
+    channel against the vector-ALU ingest kernel of the same plan."""
+    nch, n = 40000, BLK
+    rng = np.random.default_rng(808)
+    x = rng.integers(-2048, 2048, n).astype(np.int16)
+    phis = ((np.arange(nch, dtype=np.uint64) * 104729 + 605867) % (1 << 22)).astype(np.uint32)
+    row = ddc.pack_adc12(x)[None, :]
+    a = ddc.Ddc(nch)
+    a.tune_many(phis)
+    spec, voice = a.rx_process(row, n, row_bytes=0)
+    a.close()
+    b = ddc.Ddc(nch)
+    b.tune_many(phis)
+    b.debug_rx_plan(2)
+    spec2, voice2 = b.rx_process(row, n, row_bytes=0)
+    b.close()
+    assert np.array_equal(spec, spec2) and np.array_equal(voice, voice2)
+    for c in (0, 1, 32767, 32768, 32769, nch - 1):
+        ws, wv = orc.RxChain(int(phis[c])).run(x)
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
