@@ -113,10 +113,12 @@ size_t ddc_rx_static_scratch_need(uint32_t n_channels, size_t samples);
 int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples);
 /* Debug switch.  An RX call whose samples / 512 is a multiple of 256 runs as two
  * kernels (the ingest kernel forms the window sums of rx_cic on the matrix cores),
- * any other size as six smaller kernels; the results are the same bit for bit and
- * the carried state is common, so calls of both kinds may alternate.
+ * a smaller call as six smaller kernels, and any other size as both: the largest
+ * multiple of 131072 samples the first way, the remainder the second.  The results
+ * are the same bit for bit and the carried state is common, so calls (and parts of
+ * calls) of both kinds may alternate.
  * plan = 1 makes every call of this ctx use the six kernels, plan = 2 keeps the
- * choice by size but runs the two-kernel calls with the ingest kernel that stays on
+ * choice by size but runs the two-kernel parts with the ingest kernel that stays on
  * the vector ALU (both for A/B timing and for tests), plan = 0 restores the default. */
 int ddc_debug_rx_plan(ddc_ctx *ctx, int plan);
 

@@ -256,3 +256,58 @@ def test_more_channels_than_one_grid_dimension_holds(ddc, orc):
     for c in (0, 1, 32767, 32768, 32769, nch - 1):
         ws, wv = orc.RxChain(int(phis[c])).run(x)
         assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+
+
+@pytest.mark.parametrize("extra", [1024, 5 * 1024, 127 * 1024])
+@pytest.mark.parametrize("n_wg", [1, 9])
+def test_any_size_runs_as_a_two_kernel_part_and_a_remainder(ddc, orc, n_wg, extra):
+    """A call of n_wg * 131072 + extra samples: the library runs the multiple of 131072 as two
+    kernels and the rest as six, both writing into the rows of the whole call.  Outputs, the raw
+    rx_cic tap and the carried state against the oracle and against the six-kernel plan alone,
+    over two calls; the entry point that allocates nothing does the same inside its fixed area."""
+    torch = pytest.importorskip("torch")
+    n = n_wg * BLK + extra
+    nch = 3
+    rng = np.random.default_rng(n_wg * 1000 + extra)
+    chans = [rng.integers(-2048, 2048, 2 * n).astype(np.int16) for _ in range(nch)]
+    phis = [605867, 3 << 20, 4194303]
+    d = ddc.Ddc(nch)
+    d.tune_many(phis)
+    e = ddc.Ddc(nch)
+    e.tune_many(phis)
+    e.debug_rx_plan(1)
+    outs = []
+    for k in range(2):
+        rows = rows_of(ddc, [x[k * n:(k + 1) * n] for x in chans])
+        sp, vo = d.rx_process(rows, n)
+        cic = d.rx_read_cic(n)
+        sp2, vo2 = e.rx_process(rows, n)
+        cic2 = e.rx_read_cic(n)
+        assert np.array_equal(cic, cic2), k
+        assert np.array_equal(sp, sp2) and np.array_equal(vo, vo2), k
+        outs.append((sp, vo))
+    spec = np.concatenate([o[0] for o in outs], axis=1)
+    voice = np.concatenate([o[1] for o in outs], axis=1)
+    for c in range(nch):
+        ws, wv = orc.RxChain(phis[c]).run(chans[c])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), c
+        assert d.rx_get_phase(c) == e.rx_get_phase(c) == (phis[c] * 2 * n) & 0x3FFFFF
+    d.close()
+    e.close()
+    # the same through the static work area
+    s = ddc.Ddc(nch)
+    s.tune_many(phis)
+    L = ddc.lib()
+    assert L.ddc_rx_static_scratch_need(nch, n) <= L.ddc_rx_static_scratch_bytes()
+    rb = n // 2 * 3
+    out = torch.zeros((2, nch, n // 1024, 2), dtype=torch.int16, device="cuda")
+    got = []
+    for k in range(2):
+        adc = torch.from_numpy(rows_of(ddc, [x[k * n:(k + 1) * n] for x in chans])).cuda()
+        torch.cuda.synchronize()
+        s.rx_process_dev_static(adc.data_ptr(), rb, n, out[0].data_ptr(), out[1].data_ptr())
+        s.sync()
+        got.append(out.cpu().numpy().copy())
+    assert np.array_equal(np.concatenate([g[0] for g in got], axis=1), spec)
+    assert np.array_equal(np.concatenate([g[1] for g in got], axis=1), voice)
+    s.close()

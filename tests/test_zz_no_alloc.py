@@ -61,16 +61,18 @@ def test_static_work_area_matches_growing_buffers(ddc, orc):
 def test_static_work_area_rejects_oversized_calls(ddc):
     torch = pytest.importorskip("torch")
     L = ddc.lib()
-    # 1024 channels x 2^20 samples (the bench shape) runs as one kernel and fits (about 15 MB);
-    # the same samples plus 1024 go the separate-kernel way, whose window moments alone are 176 MB
+    # 1024 channels x 2^20 samples (the bench shape) runs as two kernels and fits (about 15 MB), and
+    # so does the same plus 1024 samples (two kernels and a small remainder as six); four times
+    # the samples do not, nor do 4096 channels x 254 blocks, which go the six-kernel way whole
+    # (80 bytes of window moments per block)
     n_ch, n = 1024, 1 << 20
-    assert L.ddc_rx_static_scratch_need(n_ch, n) <= L.ddc_rx_static_scratch_bytes()
-    assert L.ddc_rx_static_scratch_need(n_ch, n + 1024) > L.ddc_rx_static_scratch_bytes()
+    assert L.ddc_rx_static_scratch_need(n_ch, n) <= L.ddc_rx_static_scratch_need(n_ch, n + 1024) <= L.ddc_rx_static_scratch_bytes()
     assert L.ddc_rx_static_scratch_need(n_ch, 4 * n) > L.ddc_rx_static_scratch_bytes()
+    assert L.ddc_rx_static_scratch_need(4 * n_ch, 254 * 512) > L.ddc_rx_static_scratch_bytes()
     d = ddc.Ddc(n_ch)
     adc = torch.zeros((16,), dtype=torch.uint8, device="cuda")   # never read: the call must refuse first
     out = torch.zeros((16,), dtype=torch.int16, device="cuda")
-    for samples in (n + 1024, 4 * n):
+    for samples in (4 * n, 8 * n + 1024):
         with pytest.raises(ddc.DdcError, match="work area"):
             d.rx_process_dev_static(adc.data_ptr(), samples // 2 * 3, samples, out.data_ptr(), out.data_ptr())
     d.close()

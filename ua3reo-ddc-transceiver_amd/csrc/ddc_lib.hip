@@ -53,8 +53,10 @@ struct ddc_ctx {
     uint4 *d_mx_tab = nullptr;   // byte planes of the window-moment weights (ddc_rx_front_mx)
     // work buffers, sized for cap_blk blocks of 512 samples per channel
     uint32_t cap_blk = 0;
-    uint32_t last_blk = 0;
-    const int16_t *last_cic = nullptr; // rx_cic outputs of the last RX call (work buffer or static area)
+    // rx_cic outputs of the last RX call (work buffer or static area): one piece per part the call ran as
+    uint32_t last_blk = 0;             // blocks of the whole call
+    uint32_t last_part_blk[2] = {0, 0};
+    const int16_t *last_cic = nullptr, *last_cic2 = nullptr;
     unsigned char *scratch_base = nullptr; // this device's copy of the static work area
     unsigned long long *d_mom = nullptr;
     int16_t *d_cic = nullptr;
@@ -181,7 +183,7 @@ int ensure_capacity(ddc_ctx *ctx, uint32_t n_blk)
     if (ctx->d_cic) (void)hipFree(ctx->d_cic);
     if (ctx->d_comp) (void)hipFree(ctx->d_comp);
     ctx->d_mom = nullptr; ctx->d_cic = nullptr; ctx->d_comp = nullptr; ctx->cap_blk = 0;
-    ctx->last_cic = nullptr; ctx->last_blk = 0; // the debug tap must not read a freed buffer if the call fails later
+    ctx->last_cic = ctx->last_cic2 = nullptr; ctx->last_blk = 0; // the debug tap must not read a freed buffer if the call fails later
     HIP_TRY(ctx, hipMalloc(&ctx->d_mom, nch * (ddc::kMomHist + (size_t)n_blk) * 10 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_cic, nch * (ddc::kCicHist + (size_t)n_blk) * 2 * sizeof(int16_t)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_comp, nch * (ddc::kCompHist + (size_t)n_blk / 2) * 2 * sizeof(int16_t)));
@@ -214,7 +216,7 @@ int ensure_fused_capacity(ddc_ctx *ctx, uint32_t n_blk)
     if (ctx->d_comp_tail) (void)hipFree(ctx->d_comp_tail);
     ctx->d_comp_tail = nullptr;
     ctx->d_cicf = nullptr; ctx->d_edge = nullptr; ctx->d_cnt = nullptr; ctx->cap_fused_blk = 0; ctx->cnt_words = 0;
-    ctx->last_cic = nullptr; ctx->last_blk = 0;
+    ctx->last_cic = ctx->last_cic2 = nullptr; ctx->last_blk = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_cicf, f.cic));
     HIP_TRY(ctx, hipMalloc(&ctx->d_edge, f.edge));
     HIP_TRY(ctx, hipMalloc(&ctx->d_comp_tail, f.tail));
@@ -302,7 +304,8 @@ void device_tables_mark_ready(int device)
 constexpr size_t kStaticCntBytes = 256u << 10;
 struct WorkLayout { bool fused; size_t mom, cic, comp, edge, tail, cnt_words, total; };
 bool plan_is_fused(int rx_plan, size_t n_blk) { return rx_plan != 1 && n_blk % ddc::kFrontThreads == 0; }
-WorkLayout work_layout(size_t nch, size_t n_blk, bool fused)
+// (first: bytes behind the counters that an earlier part of the same call occupies)
+WorkLayout work_layout(size_t nch, size_t n_blk, bool fused, size_t first = 0)
 {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     WorkLayout w{};
@@ -310,14 +313,14 @@ WorkLayout work_layout(size_t nch, size_t n_blk, bool fused)
     if (fused) {
         const FusedLayout f = fused_layout(nch, n_blk);
         w.cnt_words = f.cnt_words;
-        w.cic = kStaticCntBytes;
+        w.cic = kStaticCntBytes + first;
         w.edge = w.cic + up(f.cic);
         w.tail = w.edge + up(f.edge);
         w.total = w.tail + up(f.tail);
         if (f.cnt_words * 4 > kStaticCntBytes) w.total = (size_t)-1; // more counters than the reserved block holds
         return w;
     }
-    w.mom = kStaticCntBytes;
+    w.mom = kStaticCntBytes + first;
     w.cic = w.mom + up(nch * (ddc::kMomHist + n_blk) * 10 * sizeof(unsigned long long));
     w.comp = w.cic + up(nch * (ddc::kCicHist + n_blk) * 2 * sizeof(int16_t));
     w.total = w.comp + up(nch * (ddc::kCompHist + n_blk / 2) * 2 * sizeof(int16_t));
@@ -749,11 +752,16 @@ static int rx_check_args(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, s
 // events to record around the ingest kernel and the rest, or null.
 //
 // Two call plans, same arithmetic: block counts that are a multiple of 256 run as two
-// kernels (ddc_rx_front_cic: a workgroup owns 256 windows of one channel and combines them
-// into rx_cic outputs itself; ddc_rx_tail: the 48 kHz stages and the state hand-over, one
-// workgroup per 1024 frames); any other block count runs the six separate kernels.
+// kernels (ddc_rx_front_mx, or ddc_rx_front_cic under plan 2: a workgroup owns 256 windows of
+// one channel and combines them into rx_cic outputs itself; ddc_rx_tail: the 48 kHz stages and
+// the state hand-over, one workgroup per 1024 frames); any other block count runs the six
+// separate kernels.  rx_split cuts a larger call of any size into a part of the first kind and a
+// remainder of the second: the carried state is common to both plans, so the two parts are two
+// calls on one stream of samples.
+// out_pitch: frames per channel row of spec_iq / voice_iq (a call that runs in two parts writes both
+// into the rows of the whole call).
 static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples, uint32_t n_blk,
-                     int16_t *spec_iq, int16_t *voice_iq, bool fused, const RxWork &w, hipEvent_t *pev)
+                     int16_t *spec_iq, int16_t *voice_iq, uint32_t out_pitch, bool fused, const RxWork &w, hipEvent_t *pev)
 {
     const uint32_t nch = ctx->cfg.n_channels, total = n_blk * nch, nf = n_blk / 2;
     hipStream_t st = ctx->stream;
@@ -767,6 +775,7 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
         fa.phi32v = ctx->d_phi;
         fa.spec_iq = spec_iq; fa.voice_iq = voice_iq;
         fa.n_wg = (uint32_t)f.n_wg; fa.n_tiles = (uint32_t)f.n_tiles; fa.samples_lo = (uint32_t)samples;
+        fa.out_pitch = out_pitch;
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[0], st));
         if (ctx->rx_plan == 2)
             ddc::ddc_rx_front_cic<<<total / ddc::kFrontThreads, ddc::kFrontThreads, 0, st>>>(adc12, row_bytes, n_blk, total,
@@ -793,8 +802,8 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
         const uint32_t ctiles = (n_blk + 255) / 256;
         ddc::ddc_rx_cic_combine<<<nch * ctiles, 256, 0, st>>>(w.mom, n_blk, ctiles, w.cic);
         const uint32_t tiles = (nf + ddc::kTailTile - 1) / ddc::kTailTile;
-        ddc::ddc_rx_ciccomp<<<nch * tiles, 256, 0, st>>>(w.cic, n_blk, tiles, w.comp, spec_iq);
-        ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(w.comp, nf, tiles, voice_iq);
+        ddc::ddc_rx_ciccomp<<<nch * tiles, 256, 0, st>>>(w.cic, n_blk, tiles, w.comp, spec_iq, out_pitch);
+        ddc::ddc_rx_hilbert<<<nch * tiles, 256, 0, st>>>(w.comp, nf, tiles, voice_iq, out_pitch);
         ddc::ddc_rx_save_history<<<nch, 256, 0, st>>>(ctx->d_hist_mom, ctx->d_hist_cic, ctx->d_hist_comp, w.mom, w.cic,
                                                      w.comp, ctx->d_acc, ctx->d_phi, n_blk, (uint32_t)samples);
         if (pev) HIP_TRY(ctx, hipEventRecord(pev[2], st));
@@ -809,6 +818,43 @@ static int rx_launch(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_
     return 0;
 }
 
+// The parts a call of n_blk blocks runs as: one, or (any size above 256 blocks that is not a multiple
+// of 256, unless plan 1 is forced) the largest multiple of 256 blocks as two kernels and the rest as six.
+struct RxPart { uint32_t n_blk; bool fused; };
+static int rx_split(int rx_plan, uint32_t n_blk, RxPart part[2])
+{
+    if (rx_plan != 1 && n_blk > (uint32_t)ddc::kFrontThreads && n_blk % ddc::kFrontThreads) {
+        const uint32_t main_blk = n_blk / ddc::kFrontThreads * ddc::kFrontThreads;
+        part[0] = RxPart{ main_blk, true };
+        part[1] = RxPart{ n_blk - main_blk, false };
+        return 2;
+    }
+    part[0] = RxPart{ n_blk, plan_is_fused(rx_plan, n_blk) };
+    part[1] = RxPart{ 0, false };
+    return 1;
+}
+
+// Queues the parts of one call, each on its stretch of the input rows and of the output rows.
+static int rx_run(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, uint32_t n_blk, int16_t *spec_iq, int16_t *voice_iq,
+                  const RxPart *part, int n_parts, const RxWork *w, hipEvent_t *pev)
+{
+    size_t blk0 = 0;
+    for (int k = 0; k < n_parts; k++) {
+        // blk0 blocks = blk0 / 2 frames of two int16 each
+        const int rc = rx_launch(ctx, adc12 + blk0 * ddc::kBlkBytes, row_bytes, (size_t)part[k].n_blk * 512, part[k].n_blk,
+                                 spec_iq + blk0, voice_iq + blk0, n_blk / 2, part[k].fused, w[k], k == 0 ? pev : nullptr);
+        if (rc) return rc;
+        blk0 += part[k].n_blk;
+    }
+    if (pev && n_parts > 1) HIP_TRY(ctx, hipEventRecord(pev[2], ctx->stream)); // the rest of the call ends behind the last part
+    ctx->last_blk = n_blk;
+    ctx->last_part_blk[0] = part[0].n_blk;
+    ctx->last_part_blk[1] = n_parts > 1 ? part[1].n_blk : 0;
+    ctx->last_cic = w[0].cic;
+    ctx->last_cic2 = n_parts > 1 ? w[1].cic : nullptr;
+    return 0;
+}
+
 int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
                        int16_t *spec_iq, int16_t *voice_iq)
 {
@@ -818,9 +864,12 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
     int rc = rx_check_args(ctx, adc12, row_bytes, samples, spec_iq, voice_iq, &n_blk);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    const bool fused = plan_is_fused(ctx->rx_plan, n_blk);
-    rc = fused ? ensure_fused_capacity(ctx, n_blk) : ensure_capacity(ctx, n_blk);
-    if (rc) return rc;
+    RxPart part[2];
+    const int n_parts = rx_split(ctx->rx_plan, n_blk, part);
+    for (int k = 0; k < n_parts; k++) {
+        rc = part[k].fused ? ensure_fused_capacity(ctx, part[k].n_blk) : ensure_capacity(ctx, part[k].n_blk);
+        if (rc) return rc;
+    }
     hipEvent_t *pev = nullptr;
     if (ctx->profile) {
         pev = ctx->ev[ctx->prof_head];
@@ -829,20 +878,35 @@ int ddc_rx_process_dev(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, siz
         ctx->prof_head = (ctx->prof_head + 1) % ddc_ctx::kProfRing;
         if (ctx->prof_count < ddc_ctx::kProfRing) ctx->prof_count++;
     }
-    const RxWork w = fused ? RxWork{ nullptr, ctx->d_cicf, nullptr, ctx->d_edge, ctx->d_comp_tail, ctx->d_cnt }
-                           : RxWork{ ctx->d_mom, ctx->d_cic, ctx->d_comp, nullptr, nullptr, nullptr };
-    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq, fused, w, pev);
-    if (rc) return rc;
-    ctx->last_blk = n_blk;
-    ctx->last_cic = w.cic;
-    return 0;
+    RxWork w[2];
+    for (int k = 0; k < n_parts; k++)
+        w[k] = part[k].fused ? RxWork{ nullptr, ctx->d_cicf, nullptr, ctx->d_edge, ctx->d_comp_tail, ctx->d_cnt }
+                             : RxWork{ ctx->d_mom, ctx->d_cic, ctx->d_comp, nullptr, nullptr, nullptr };
+    return rx_run(ctx, adc12, row_bytes, n_blk, spec_iq, voice_iq, part, n_parts, w, pev);
 }
 
 size_t ddc_rx_static_scratch_bytes(void) { return DDC_STATIC_SCRATCH_BYTES; }
 
+// Work areas of the parts of a call inside the static area, one behind the other (the arrival
+// counters at the start of the area are only ever the two-kernel part's).
+static size_t static_layout(int rx_plan, uint32_t n_channels, uint32_t n_blk, RxPart part[2], int *n_parts, WorkLayout lay[2])
+{
+    *n_parts = rx_split(rx_plan, n_blk, part);
+    size_t off = 0;
+    for (int k = 0; k < *n_parts; k++) {
+        lay[k] = work_layout(n_channels, part[k].n_blk, part[k].fused, off);
+        if (lay[k].total == (size_t)-1) return (size_t)-1;
+        off = lay[k].total - kStaticCntBytes;
+    }
+    return lay[*n_parts - 1].total;
+}
+
 size_t ddc_rx_static_scratch_need(uint32_t n_channels, size_t samples)
 {
-    return work_layout(n_channels, samples / 512, plan_is_fused(0, samples / 512)).total;
+    RxPart part[2];
+    WorkLayout lay[2];
+    int n_parts = 0;
+    return static_layout(0, n_channels, (uint32_t)(samples / 512), part, &n_parts, lay);
 }
 
 int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_bytes, size_t samples,
@@ -853,32 +917,34 @@ int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_byt
     uint32_t n_blk = 0;
     int rc = rx_check_args(ctx, adc12, row_bytes, samples, spec_iq, voice_iq, &n_blk);
     if (rc) return rc;
-    const bool fused = plan_is_fused(ctx->rx_plan, n_blk);
-    const WorkLayout w = work_layout(ctx->cfg.n_channels, n_blk, fused);
-    if (w.total > DDC_STATIC_SCRATCH_BYTES) {
+    RxPart part[2];
+    WorkLayout lay[2];
+    int n_parts = 0;
+    const size_t need = static_layout(ctx->rx_plan, ctx->cfg.n_channels, n_blk, part, &n_parts, lay);
+    if (need > DDC_STATIC_SCRATCH_BYTES) {
         char msg[200];
-        if (w.total == (size_t)-1)
+        if (need == (size_t)-1)
             snprintf(msg, sizeof msg, "ddc_rx_process_dev_static: %u channels x %zu samples need more arrival counters "
                      "than the static work area reserves (%zu bytes)", ctx->cfg.n_channels, samples, kStaticCntBytes);
         else
             snprintf(msg, sizeof msg, "ddc_rx_process_dev_static: %u channels x %zu samples need %zu bytes of work area, "
-                     "the static one holds %u", ctx->cfg.n_channels, samples, w.total, DDC_STATIC_SCRATCH_BYTES);
+                     "the static one holds %u", ctx->cfg.n_channels, samples, need, DDC_STATIC_SCRATCH_BYTES);
         return fail(ctx, -E2BIG, msg);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
     unsigned char *base = ctx->scratch_base; // resolved by ddc_create on this ctx's device
     if (!base) return fail(ctx, -EFAULT, "static work area was not resolved when the ctx was created");
-    const RxWork rw = fused ? RxWork{ nullptr, reinterpret_cast<int16_t *>(base + w.cic), nullptr,
-                                      reinterpret_cast<unsigned long long *>(base + w.edge),
-                                      reinterpret_cast<uint32_t *>(base + w.tail), reinterpret_cast<uint32_t *>(base) }
-                            : RxWork{ reinterpret_cast<unsigned long long *>(base + w.mom),
-                                      reinterpret_cast<int16_t *>(base + w.cic),
-                                      reinterpret_cast<int16_t *>(base + w.comp), nullptr, nullptr, nullptr };
-    rc = rx_launch(ctx, adc12, row_bytes, samples, n_blk, spec_iq, voice_iq, fused, rw, nullptr);
-    if (rc) return rc;
-    ctx->last_blk = n_blk;
-    ctx->last_cic = rw.cic;
-    return 0;
+    RxWork rw[2];
+    for (int k = 0; k < n_parts; k++) {
+        const WorkLayout &l = lay[k];
+        rw[k] = part[k].fused ? RxWork{ nullptr, reinterpret_cast<int16_t *>(base + l.cic), nullptr,
+                                        reinterpret_cast<unsigned long long *>(base + l.edge),
+                                        reinterpret_cast<uint32_t *>(base + l.tail), reinterpret_cast<uint32_t *>(base) }
+                              : RxWork{ reinterpret_cast<unsigned long long *>(base + l.mom),
+                                        reinterpret_cast<int16_t *>(base + l.cic),
+                                        reinterpret_cast<int16_t *>(base + l.comp), nullptr, nullptr, nullptr };
+    }
+    return rx_run(ctx, adc12, row_bytes, n_blk, spec_iq, voice_iq, part, n_parts, rw, nullptr);
 }
 
 /* Debug switch: plan 0 picks the call plan by shape (two kernels when samples / 512 is a
@@ -935,9 +1001,16 @@ int ddc_rx_read_cic(ddc_ctx *ctx, int16_t *cic_iq, size_t samples)
     const uint32_t n_blk = (uint32_t)(samples / 512);
     if (n_blk == 0 || n_blk != ctx->last_blk) return fail(ctx, -EINVAL, "ddc_rx_read_cic: size differs from the last call");
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    HIP_TRY(ctx, hipMemcpy2DAsync(cic_iq, (size_t)n_blk * 4, ctx->last_cic + (size_t)ddc::kCicHist * 2,
-                                  (size_t)(ddc::kCicHist + n_blk) * 4, (size_t)n_blk * 4, ctx->cfg.n_channels,
-                                  hipMemcpyDeviceToHost, ctx->stream));
+    const int16_t *src[2] = { ctx->last_cic, ctx->last_cic2 };
+    size_t blk0 = 0;
+    for (int k = 0; k < 2; k++) { // the parts the call ran as, each with its own work buffer
+        const uint32_t pb = ctx->last_part_blk[k];
+        if (!pb || !src[k]) continue;
+        HIP_TRY(ctx, hipMemcpy2DAsync(cic_iq + blk0 * 2, (size_t)n_blk * 4, src[k] + (size_t)ddc::kCicHist * 2,
+                                      (size_t)(ddc::kCicHist + pb) * 4, (size_t)pb * 4, ctx->cfg.n_channels,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        blk0 += pb;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -565,6 +565,7 @@ struct RxFused {
     const uint32_t *phi32v;
     int16_t *spec_iq, *voice_iq;
     uint32_t n_wg, n_tiles, samples_lo;
+    uint32_t out_pitch; // frames per channel row of spec_iq / voice_iq (at least the call's own frame count)
 };
 
 // byte offsets into the 32 KB line buffer while a tile runs
@@ -703,7 +704,7 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
 
     // compensator outputs of frames f_lo .. n1 - 1
     const uint32_t f_lo = n0 - (halo ? 256u : 0u), n_out = n1 - f_lo;
-    uint32_t *spec32 = reinterpret_cast<uint32_t *>(fa.spec_iq) + (size_t)ch * nf;
+    uint32_t *spec32 = reinterpret_cast<uint32_t *>(fa.spec_iq) + (size_t)ch * fa.out_pitch;
 #pragma unroll 1
     for (uint32_t o = 4 * t; o < n_out; o += 1024) {
         uint32_t packed[4];
@@ -741,7 +742,7 @@ __device__ __forceinline__ void rx_tile_finish(const RxFused &fa, uint32_t ch, u
     int S[4];
     hilbert_quad_sums(reinterpret_cast<const uint4 *>(xa) + par * (kHilbIn / 8) + g,
                       reinterpret_cast<const uint32_t *>(lds + kLdsTaps), S);
-    uint32_t *voice32 = reinterpret_cast<uint32_t *>(fa.voice_iq) + (size_t)ch * nf;
+    uint32_t *voice32 = reinterpret_cast<uint32_t *>(fa.voice_iq) + (size_t)ch * fa.out_pitch;
     int16_t vi[4];
     hilbert_round4(S, 8 * g + par, p0, p1, vi);
 #pragma unroll
@@ -1187,10 +1188,10 @@ __global__ __launch_bounds__(256) void ddc_adc_minmax(const uint8_t *__restrict_
 /*
  * Kernel 3 of the call plan with separate kernels.  rx_ciccomp (ciccomp_quad) for
  * 1024 consecutive outputs of one channel per workgroup; writes SPEC I/Q to the
- * caller and to comp: [channel][kCompHist + nf][2].
+ * caller (rows out_pitch frames apart) and to comp: [channel][kCompHist + nf][2].
  */
 __global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict__ cic, uint32_t n_blk, uint32_t tiles,
-                                                     int16_t *__restrict__ comp, int16_t *__restrict__ spec_iq)
+                                                     int16_t *__restrict__ comp, int16_t *__restrict__ spec_iq, uint32_t out_pitch)
 {
     constexpr int kIn = 2 * kTailTile + 64;          // samples staged per branch: 2 n0 - 64 .. 2 n0 + 2047
     __shared__ __align__(16) int16_t si[kIn + 8], sq[kIn + 8];
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict_
     const uint32_t n = n0 + 4 * t;
     if (n >= nf) return;
     uint32_t *oc = reinterpret_cast<uint32_t *>(comp) + (size_t)ch * (kCompHist + nf) + kCompHist + n;
-    uint32_t *os = reinterpret_cast<uint32_t *>(spec_iq) + (size_t)ch * nf + n;
+    uint32_t *os = reinterpret_cast<uint32_t *>(spec_iq) + (size_t)ch * out_pitch + n;
     if (n + 3 < nf && (nf & 3u) == 0 && ((uintptr_t)os & 15u) == 0) { // whole quad, 16-byte aligned rows
         *reinterpret_cast<uint4 *>(oc) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
         *reinterpret_cast<uint4 *>(os) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(256) void ddc_rx_ciccomp(const int16_t *__restrict_
  * channel: waves 0-1 take the even outputs, waves 2-3 the odd ones.
  */
 __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict__ comp, uint32_t nf, uint32_t tiles,
-                                                     int16_t *__restrict__ voice_iq)
+                                                     int16_t *__restrict__ voice_iq, uint32_t out_pitch)
 {
     __shared__ __align__(16) uint32_t xs[2][kHilbIn / 2]; // [0]: pairs (2m, 2m+1), [1]: pairs (2m+1, 2m+2)
     __shared__ uint32_t p0[kHilbIn / 32 + 2], p1[kHilbIn / 32 + 2];
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(256) void ddc_rx_hilbert(const int16_t *__restrict_
         const uint32_t o = 8 * g + par + 2 * k, n = n0 + o;
         if (n >= nf) continue;
         const int16_t vq = (int16_t)((int)x[kCompHist + n - 130] >> 16);
-        reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * nf + n] =
+        reinterpret_cast<uint32_t *>(voice_iq)[(size_t)ch * out_pitch + n] =
             (uint32_t)(uint16_t)vi[k] | ((uint32_t)(uint16_t)vq << 16);
     }
 }
