@@ -19,6 +19,12 @@
  * Kernel 1 (ddc_rx_front) is the only one that touches the ADC stream; it is
  * bound by vector-ALU issue (about 18 vector instructions per sample), reads every
  * ADC byte once (1.5 B per sample) and writes 80 B of moments per 512 samples.
+ * ddc_rx_front_cic is the same kernel for block counts that are a multiple of 256:
+ * it also turns the moments into rx_cic outputs.  ddc_rx_front_mx
+ * (ddc_rx_mx_kernel.hip.h) does what ddc_rx_front_cic does with the moment sums on
+ * the matrix cores (about 14 vector instructions per sample) and is what the
+ * library runs for such block counts; it shares the NCO, mixer and unpack code and
+ * the rx_cic epilogue below.
  */
 #pragma once
 #include <hip/hip_runtime.h>
