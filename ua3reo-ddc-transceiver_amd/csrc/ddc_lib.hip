@@ -947,8 +947,9 @@ int ddc_rx_process_dev_static(ddc_ctx *ctx, const uint8_t *adc12, size_t row_byt
     return rx_run(ctx, adc12, row_bytes, n_blk, spec_iq, voice_iq, part, n_parts, rw, nullptr);
 }
 
-/* Debug switch: plan 0 picks the call plan by shape (two kernels when samples / 512 is a
- * multiple of 256), plan 1 always runs the separate kernels.  Same results either way. */
+/* Debug switch: plan 0 picks the call plan by shape (two kernels for every multiple of 256 blocks
+ * in a call, six for what is left), plan 1 always runs the six kernels, plan 2 is plan 0 with the
+ * vector-ALU ingest kernel in the two-kernel parts.  Same results every way. */
 int ddc_debug_rx_plan(ddc_ctx *ctx, int plan)
 {
     if (!ctx) return -EINVAL;
