@@ -86,29 +86,33 @@ inline bool build_mx_table(uint8_t *tab /* kMxTabBytes */)
     return true;
 }
 
-// eight samples: NCO, mixer, packed pairs {2 x_even | 2 x_odd << 16} per branch
-// (phi2_last: what the phase pair advances by behind the last two samples)
-__device__ __forceinline__ void mx_group8(const uint2 *tab, uint32_t d0, uint32_t d1, uint32_t d2,
-                                          unsigned long long &accp, unsigned long long phi2, unsigned long long phi2_last,
-                                          unsigned *pi, unsigned *pq)
+// Four samples at a time, in two halves, so that the table fetches of one group of four are under
+// way while the group before is being mixed (a wave would otherwise sit out an LDS round trip per
+// group): mx_quad_fetch makes the table addresses and fine-sine operands and issues the fetches,
+// mx_quad_finish does the angle sums, the products and the packed pairs {2 x_even | 2 x_odd << 16}.
+struct MxQuad {
+    uint2 e[4];
+    uint32_t w[4];
+};
+// (phi2_b: what the phase pair advances by behind the group's last two samples)
+__device__ __forceinline__ void mx_quad_fetch(const uint2 *tab, unsigned long long &accp, unsigned long long phi2,
+                                              unsigned long long phi2_b, MxQuad &q)
 {
-    int a[8];
-    unpack8(d0, d1, d2, a);
-    uint2 e[8];
-    uint32_t w[8];
     unsigned long long p = accp;
+    nco_fetch(tab, (uint32_t)p, q.e[0], q.w[0]);
+    nco_fetch(tab, (uint32_t)(p >> 32), q.e[1], q.w[1]);
+    p = pair_add(p, phi2);
+    nco_fetch(tab, (uint32_t)p, q.e[2], q.w[2]);
+    nco_fetch(tab, (uint32_t)(p >> 32), q.e[3], q.w[3]);
+    accp = pair_add(p, phi2_b);
+}
+__device__ __forceinline__ void mx_quad_finish(const MxQuad &q, const int *a, unsigned *pi, unsigned *pq)
+{
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        nco_fetch(tab, (uint32_t)p, e[2 * k], w[2 * k]);
-        nco_fetch(tab, (uint32_t)(p >> 32), e[2 * k + 1], w[2 * k + 1]);
-        p = pair_add(p, k == 3 ? phi2_last : phi2);
-    }
-    accp = p;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 2; k++) {
         int pi0, pq0, pi1, pq1;
-        nco_finish(e[2 * k], w[2 * k], a[2 * k], pi0, pq0);
-        nco_finish(e[2 * k + 1], w[2 * k + 1], a[2 * k + 1], pi1, pq1);
+        nco_finish(q.e[2 * k], q.w[2 * k], a[2 * k], pi0, pq0);
+        nco_finish(q.e[2 * k + 1], q.w[2 * k + 1], a[2 * k + 1], pi1, pq1);
         pi[k] = pack_x2(pi0, pi1);
         pq[k] = pack_x2(pq0, pq1);
     }
@@ -246,6 +250,9 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
         v4i aih, ail, aqh, aql;
         int hi_i[4], lo_i[4], hi_q[4], lo_q[4];
         uint2 nx0 = make_uint2(0, 0), nx1 = make_uint2(0, 0), nx2 = make_uint2(0, 0);
+        MxQuad qa, qb;
+        mx_quad_fetch(tab, accp, phi2, phi2, qa);
+        mx_quad_fetch(tab, accp, phi2, phi2, qb);
 #pragma unroll
         for (int hc = 0; hc < 8; hc++) {
             const int h = hc >> 2, c = hc & 3;
@@ -269,8 +276,26 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
             const uint4 wa = *reinterpret_cast<const uint4 *>(wrow + 1024 * hc);
             const v4i A = { (int)wa.x, (int)wa.y, (int)wa.z, (int)wa.w };
             unsigned pi[8], pq[8];
-            mx_group8(tab, v0.x, v0.y, v1.x, accp, phi2, phi2, pi, pq);
-            mx_group8(tab, v1.y, v2.x, v2.y, accp, phi2, phi50, pi + 4, pq + 4);
+            {
+                // two groups of four are always under way: the step's first two were fetched behind
+                // the step before (its phase does not need the samples), the next step's go out here
+                int a[8], a2[8];
+                unpack8(v0.x, v0.y, v1.x, a);
+                unpack8(v1.y, v2.x, v2.y, a2);
+                __builtin_amdgcn_sched_barrier(0);
+                mx_quad_finish(qa, a, pi, pq);
+                mx_quad_fetch(tab, accp, phi2, phi2, qa);
+                __builtin_amdgcn_sched_barrier(0);
+                mx_quad_finish(qb, a + 4, pi + 2, pq + 2);
+                mx_quad_fetch(tab, accp, phi2, phi50, qb);
+                __builtin_amdgcn_sched_barrier(0);
+                mx_quad_finish(qa, a2, pi + 4, pq + 4);
+                if (hc < 7) mx_quad_fetch(tab, accp, phi2, phi2, qa);
+                __builtin_amdgcn_sched_barrier(0);
+                mx_quad_finish(qb, a2 + 4, pi + 6, pq + 6);
+                if (hc < 7) mx_quad_fetch(tab, accp, phi2, phi2, qb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 mx_planes(pi[2 * m], pi[2 * m + 1], hi_i[m], lo_i[m]);
