@@ -89,7 +89,8 @@ inline bool build_mx_table(uint8_t *tab /* kMxTabBytes */)
 // Four samples at a time, in two halves, so that the table fetches of one group of four are under
 // way while the group before is being mixed (a wave would otherwise sit out an LDS round trip per
 // group): mx_quad_fetch makes the table addresses and fine-sine operands and issues the fetches,
-// mx_quad_finish does the angle sums, the products and the packed pairs {2 x_even | 2 x_odd << 16}.
+// mx_quad_finish does the angle sums, the products and the packed pairs {2 x_even | 2 x_odd << 16}
+// (bit 0 of either half undefined, see mx_pack4).
 struct MxQuad {
     uint2 e[4];
     uint32_t w[4];
@@ -106,21 +107,35 @@ __device__ __forceinline__ void mx_quad_fetch(const uint2 *tab, unsigned long lo
     nco_fetch(tab, (uint32_t)(p >> 32), q.e[3], q.w[3]);
     accp = pair_add(p, phi2_b);
 }
+// Four mixer products of one branch -> two packed pairs.  The doubling that takes the 23-bit wrap
+// (see pack_x2) is one 64-bit shift for all four: what crosses a 16-bit boundary is the bit the
+// doubling drops, and it lands in bit 0 of the field above, which is zero in 2 x and which
+// mx_planes does not read.  A pair that leaves the kernel is cleaned with mx_pair_clean.
+__device__ __forceinline__ void mx_pack4(int p0, int p1, int p2, int p3, unsigned &pk0, unsigned &pk1)
+{
+    const unsigned y0 = __builtin_amdgcn_perm((unsigned)p1, (unsigned)p0, 0x06050201u);
+    const unsigned y1 = __builtin_amdgcn_perm((unsigned)p3, (unsigned)p2, 0x06050201u);
+    const unsigned long long y = (unsigned long long)y0 | ((unsigned long long)y1 << 32);
+    unsigned long long r;
+    asm("v_lshl_add_u64 %0, %1, 1, 0" : "=v"(r) : "v"(y));
+    pk0 = (unsigned)r;
+    pk1 = (unsigned)(r >> 32);
+}
+__device__ __forceinline__ unsigned mx_pair_clean(unsigned pk) { return pk & 0xFFFEFFFEu; }
+
 __device__ __forceinline__ void mx_quad_finish(const MxQuad &q, const int *a, unsigned *pi, unsigned *pq)
 {
+    int i[4], v[4];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        int pi0, pq0, pi1, pq1;
-        nco_finish(q.e[2 * k], q.w[2 * k], a[2 * k], pi0, pq0);
-        nco_finish(q.e[2 * k + 1], q.w[2 * k + 1], a[2 * k + 1], pi1, pq1);
-        pi[k] = pack_x2(pi0, pi1);
-        pq[k] = pack_x2(pq0, pq1);
-    }
+    for (int k = 0; k < 4; k++) nco_finish(q.e[k], q.w[k], a[k], i[k], v[k]);
+    mx_pack4(i[0], i[1], i[2], i[3], pi[0], pi[1]);
+    mx_pack4(v[0], v[1], v[2], v[3], pq[0], pq[1]);
 }
 
 // Two packed pairs (four samples) -> their high bytes and the seven bits below:
-// 2 x = 256 hi + 2 lo7 with hi a signed byte (the 23-bit wrap was taken by pack_x2) and
-// lo7 = (low byte) >> 1 in 0..127 (v_lerp_u8 with zeros is a per-byte shift right).
+// 2 x = 256 hi + 2 lo7 with hi a signed byte (the 23-bit wrap was taken by the doubling) and
+// lo7 = (low byte) >> 1 in 0..127 (v_lerp_u8 with zeros is a per-byte shift right; bit 0 of
+// the low byte is not read).
 __device__ __forceinline__ void mx_planes(unsigned pk0, unsigned pk1, int &hi, int &lo)
 {
     hi = (int)__builtin_amdgcn_perm(pk1, pk0, 0x07050301u);
@@ -342,8 +357,8 @@ __global__ __launch_bounds__(kFrontThreads, 3) void ddc_rx_front_mx(
     if (kw == fa.n_wg - 1 && tid == kFrontThreads - 1) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            fa.carry_work[ch * 6 + k] = last_i[k];
-            fa.carry_work[ch * 6 + 3 + k] = last_q[k];
+            fa.carry_work[ch * 6 + k] = mx_pair_clean(last_i[k]);
+            fa.carry_work[ch * 6 + 3 + k] = mx_pair_clean(last_q[k]);
         }
     }
     // lane 0 of row 3 now holds the planes of the wave's last five samples
