@@ -372,7 +372,12 @@ __global__ void ddc_rx_save_history(unsigned long long *hm, int16_t *hc, int16_t
 __global__ void ddc_nco_fine_selfcheck(uint32_t *out)
 {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < 2048) out[f] = nco_fine_pair(f);
+    if (f < 2048) {
+        out[f] = nco_fine_pair(f);
+        uint32_t w0, w1; // the packed form, both of its halves
+        nco_fine_pair2(f, f, w0, w1);
+        out[2048 + f] = w0 == w1 ? w0 : ~0u;
+    }
 }
 
 // The kernels' NCO (coarse table in LDS, fine sine, angle sums) evaluated for a run
@@ -387,17 +392,24 @@ __global__ __launch_bounds__(256) void ddc_nco_sweep(const uint2 *__restrict__ n
         tab2[i] = nco_entry_doubled(nco_tab[i]);
     }
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const uint32_t acc30 = ((first_phase + i) & 0x3FFFFFu) << 8;
-        int s, c;
-        nco14x(tab2, acc30, s, c);
-        out[i] = (int16_t)(s >> 16);
-        out[(size_t)count + i] = (int16_t)(c >> 16);
-        // RX: the mixer multiplies the ADC sample by these two and returns the products
-        int pi, pq;
-        nco_mix(tab, acc30, 1, pi, pq);
-        out[2 * (size_t)count + i] = (int16_t)pi;
-        out[3 * (size_t)count + i] = (int16_t)pq;
+    // two consecutive phases per thread, through the pair forms the sample loops use
+    for (uint32_t i = 2 * (blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 2 * gridDim.x * blockDim.x) {
+        const uint32_t a0 = ((first_phase + i) & 0x3FFFFFu) << 8, a1 = ((first_phase + i + 1) & 0x3FFFFFu) << 8;
+        const unsigned long long php = (unsigned long long)a0 | ((unsigned long long)a1 << 32);
+        int s[2], c[2];
+        nco14x_pair(tab2, php, s, c);
+        // RX: the mixer multiplies the ADC sample by the 12-bit operands and returns the products
+        uint2 e[2];
+        uint32_t w[2];
+        nco_fetch_pair(tab, php, e[0], e[1], w[0], w[1]);
+        for (uint32_t k = 0; k < 2 && i + k < count; k++) {
+            int pi, pq;
+            nco_finish(e[k], w[k], 1, pi, pq);
+            out[i + k] = (int16_t)(s[k] >> 16);
+            out[(size_t)count + i + k] = (int16_t)(c[k] >> 16);
+            out[2 * (size_t)count + i + k] = (int16_t)pi;
+            out[3 * (size_t)count + i + k] = (int16_t)pq;
+        }
     }
 }
 
@@ -506,13 +518,13 @@ int ddc_create(const ddc_config *cfg, ddc_ctx **out)
         // the kernels compute the fine sine with a float multiply-add on a denormal: have the
         // device evaluate all 2048 phases once and compare with the host's (d_nco_tab is free until
         // the table is uploaded just below)
-        std::vector<uint32_t> got(2048);
+        std::vector<uint32_t> got(4096);
         ddc::ddc_nco_fine_selfcheck<<<8, 256, 0, ctx->stream>>>(reinterpret_cast<uint32_t *>(ctx->d_nco_tab));
         CREATE_TRY(hipGetLastError());
-        CREATE_TRY(hipMemcpyAsync(got.data(), ctx->d_nco_tab, 2048 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CREATE_TRY(hipMemcpyAsync(got.data(), ctx->d_nco_tab, 4096 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CREATE_TRY(hipStreamSynchronize(ctx->stream));
         for (uint32_t f = 0; f < 2048; f++)
-            if (got[f] != nco_fine_pair_host(f)) {
+            if (got[f] != nco_fine_pair_host(f) || got[2048 + f] != got[f]) {
                 ctx->err = "this device evaluates the NCO fine sine differently from the host (denormals flushed?)";
                 return bail(-EFAULT);
             }

@@ -130,6 +130,37 @@ __device__ __forceinline__ void nco_fetch(const uint2 *tab, uint32_t acc30, uint
     w = nco_fine_pair(f);
 }
 
+// The fine-sine operands of two phases (the even / odd pair of one 64-bit phase sum) as one
+// packed multiply-add; v_pk_fma_f32 keeps denormal operands like v_fma_f32 does (ddc_create
+// has the device evaluate both forms for every fine phase).
+typedef float nco_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nco_fine_pair2(uint32_t f0, uint32_t f1, uint32_t &w0, uint32_t &w1)
+{
+    const nco_v2f x = { __builtin_bit_cast(float, f0), __builtin_bit_cast(float, f1) };
+    const float d = __builtin_bit_cast(float, DDC_SF_FMA_D_BITS);
+    const nco_v2f r = __builtin_elementwise_fma(x, (nco_v2f){ DDC_SF_FMA_C, DDC_SF_FMA_C }, (nco_v2f){ d, d });
+    const float r0 = r.x, r1 = r.y; // (a bit_cast of a vector element reads element 0 whichever is named)
+    w0 = __builtin_bit_cast(uint32_t, r0);
+    w1 = __builtin_bit_cast(uint32_t, r1);
+}
+
+// nco_fetch for both phases of a pair (low dword: even sample, high dword: odd sample).
+__device__ __forceinline__ void nco_fetch_pair(const uint2 *tab, unsigned long long p, uint2 &e0, uint2 &e1, uint32_t &w0,
+                                               uint32_t &w1)
+{
+    const uint32_t a0 = (uint32_t)p, a1 = (uint32_t)(p >> 32);
+    uint32_t off0, off1, f0, f1;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(off0) : "v"(a0), "v"(0x3FF8u));
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(off1) : "v"(a1), "v"(0x3FF8u));
+    asm("v_bfe_u32 %0, %1, 8, 11" : "=v"(f0) : "v"(a0));
+    asm("v_bfe_u32 %0, %1, 8, 11" : "=v"(f1) : "v"(a1));
+    e0 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off0);
+    e1 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off1);
+    nco_fine_pair2(f0, f1, w0, w1);
+}
+
 // NCO second half + mixer: 2*(cc*sf + sc*8191 + 4096) has the 12-bit mixer
 // operand (14-bit output >> 2) in bits 31..16.  Returns the two 24-bit mixer
 // products adc * nco12; the CIC input is x = wrap23(product) >> 8.

@@ -95,38 +95,14 @@ struct MxQuad {
     uint2 e[4];
     uint32_t w[4];
 };
-// nco_fetch for the even / odd pair of one 64-bit phase sum: the two fine-sine multiply-adds
-// (nco_fine_pair) are one packed instruction.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void mx_fetch_pair(const uint2 *tab, unsigned long long p, uint2 &e0, uint2 &e1, uint32_t &w0,
-                                              uint32_t &w1)
-{
-    const uint32_t a0 = (uint32_t)p, a1 = (uint32_t)(p >> 32);
-    uint32_t off0, off1, f0, f1;
-    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-        : "=v"(off0) : "v"(a0), "v"(0x3FF8u));
-    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-        : "=v"(off1) : "v"(a1), "v"(0x3FF8u));
-    asm("v_bfe_u32 %0, %1, 8, 11" : "=v"(f0) : "v"(a0));
-    asm("v_bfe_u32 %0, %1, 8, 11" : "=v"(f1) : "v"(a1));
-    e0 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off0);
-    e1 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(tab) + off1);
-    const v2f x = { __builtin_bit_cast(float, f0), __builtin_bit_cast(float, f1) };
-    const float d = __builtin_bit_cast(float, DDC_SF_FMA_D_BITS);
-    const v2f r = __builtin_elementwise_fma(x, (v2f){ DDC_SF_FMA_C, DDC_SF_FMA_C }, (v2f){ d, d });
-    const float r0 = r.x, r1 = r.y; // (bit_cast of a vector element reads element 0 whichever is named)
-    w0 = __builtin_bit_cast(uint32_t, r0);
-    w1 = __builtin_bit_cast(uint32_t, r1);
-}
-
 // (phi2_b: what the phase pair advances by behind the group's last two samples)
 __device__ __forceinline__ void mx_quad_fetch(const uint2 *tab, unsigned long long &accp, unsigned long long phi2,
                                               unsigned long long phi2_b, MxQuad &q)
 {
     unsigned long long p = accp;
-    mx_fetch_pair(tab, p, q.e[0], q.e[1], q.w[0], q.w[1]);
+    nco_fetch_pair(tab, p, q.e[0], q.e[1], q.w[0], q.w[1]);
     p = pair_add(p, phi2);
-    mx_fetch_pair(tab, p, q.e[2], q.e[3], q.w[2], q.w[3]);
+    nco_fetch_pair(tab, p, q.e[2], q.e[3], q.w[2], q.w[3]);
     accp = pair_add(p, phi2_b);
 }
 // Four mixer products of one branch -> two packed pairs.  The doubling that takes the 23-bit wrap

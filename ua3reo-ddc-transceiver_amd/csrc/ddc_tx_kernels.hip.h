@@ -63,19 +63,26 @@ __global__ void ddc_tx_ciccomp(const int16_t *__restrict__ iq48k, const int16_t 
     y[1] = (uint32_t)(uint16_t)cround32(a2i, 14, 30) | ((uint32_t)(uint16_t)cround32(a2q, 14, 30) << 16);
 }
 
-// 14-bit NCO outputs for one phase (no saturation can occur: see tests).  tab2 holds
+// 14-bit NCO outputs (no saturation can occur: see tests).  tab2 holds
 // the coarse entries doubled ({4 cc | 4 sc << 16, -4 sc | 4 cc << 16}, still 16-bit) and the
 // {fine sine, 8191} operand is doubled too, so the angle sums come out times four
 // and the 14-bit values sit in the upper halves, where a multiply selects them for
 // free; s14 / c14 are returned in that form (value << 16 plus rounding remainder).
-__device__ __forceinline__ void nco14x(const uint2 *tab2, uint32_t acc30, int &s14x, int &c14x)
+// Both phases of an even / odd pair (one 64-bit phase sum) at a time: the two fine-sine
+// multiply-adds are one packed instruction and the two doublings one 64-bit shift (bit 31 of a
+// {fine sine, 8191} operand is zero, so nothing crosses between the dwords).
+__device__ __forceinline__ void nco14x_pair(const uint2 *tab2, unsigned long long php, int (&s14x)[2], int (&c14x)[2])
 {
-    uint2 e;
-    uint32_t w;
-    nco_fetch(tab2, acc30, e, w);
-    w += w;
-    s14x = dot2_sconst(e.x, w, 32768);
-    c14x = dot2_sconst(e.y, w, 32768);
+    uint2 e0, e1;
+    uint32_t w0, w1;
+    nco_fetch_pair(tab2, php, e0, e1, w0, w1);
+    const unsigned long long w = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+    unsigned long long w2;
+    asm("v_lshl_add_u64 %0, %1, 1, 0" : "=v"(w2) : "v"(w));
+    s14x[0] = dot2_sconst(e0.x, (uint32_t)w2, 32768);
+    c14x[0] = dot2_sconst(e0.y, (uint32_t)w2, 32768);
+    s14x[1] = dot2_sconst(e1.x, (uint32_t)(w2 >> 32), 32768);
+    c14x[1] = dot2_sconst(e1.y, (uint32_t)(w2 >> 32), 32768);
 }
 __device__ __forceinline__ uint2 nco_entry_doubled(uint2 e)
 {
@@ -241,11 +248,11 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint32_t sum[2];
+            int s14x[2], c14x[2];
+            nco14x_pair(tab, php, s14x, c14x);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                int s14x, c14x;
-                nco14x(tab, h ? (uint32_t)(php >> 32) : (uint32_t)php, s14x, c14x);
-                sum[h] = (uint32_t)(__mul24(wi.out14(), s14x >> 16) + __mul24(wq.out14(), c14x >> 16) + (8191 << 14));
+                sum[h] = (uint32_t)(__mul24(wi.out14(), s14x[h] >> 16) + __mul24(wq.out14(), c14x[h] >> 16) + (8191 << 14));
                 wi.next();
                 wq.next();
             }
