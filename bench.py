@@ -79,6 +79,8 @@ def parse_args(argv=None):
                     help="auto: the library picks the RX call plan by size (two kernels for the bench shapes, the ingest "
                          "kernel with the window moments on the matrix cores); valu: the same plan with the vector-ALU "
                          "ingest kernel; split: the six separate kernels; for A/B timing on one box")
+    ap.add_argument("--tune-all-hz", type=int, default=None,
+                    help="experiment: tune every channel of the ddc workload to this frequency instead of 1 MHz + 48 kHz * channel")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the per-step all-gather even with one rank (rehearses the N > 1 path on one GPU)")
     ap.add_argument("--gather", choices=["library", "torch"], default="library",
@@ -366,6 +368,8 @@ def bench_rx(args, dev, local_rank, rank, world, dist, do_gather):
         fft_bins = torch.zeros((nch, nf // 512, 256), dtype=torch.float32, device=dev)
         fft_rows = torch.zeros((nch, nf // 512, 256), dtype=torch.int16, device=dev)
     phis = [ua3reo_ddc.phrase_from_frequency(1000000 + 48000 * (chan0 + c))[0] for c in range(nch)]
+    if args.tune_all_hz is not None:  # experiment: at 0 Hz every lane fetches one NCO table entry (no LDS bank conflicts)
+        phis = [ua3reo_ddc.phrase_from_frequency(args.tune_all_hz)[0]] * nch
     ctx = ua3reo_ddc.Ddc(nch, device=local_rank)
     ctx.tune_many(phis)
     if args.rx_plan == "split":
