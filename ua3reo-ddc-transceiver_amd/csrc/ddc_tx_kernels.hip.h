@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
         }
         obuf[mine + (((uint32_t)grp & 7u) ^ swz)] = make_uint4(w[0], w[1], w[2], w[3]);
         if ((grp & 7) == 7) {
-            __syncthreads();
+            // the rows a wave flushes are its own lanes' rows: LDS operations of one wave complete in
+            // order, so the exchange needs no workgroup barrier, only that the compiler keeps the order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t line = (uint32_t)grp >> 3;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -273,7 +277,9 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
                 if (dst16[j] != 0xFFFFFFFFu)
                     reinterpret_cast<uint4 *>(dac)[(size_t)dst16[j] + line * 8u] = v;
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
