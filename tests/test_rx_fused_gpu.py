@@ -311,3 +311,45 @@ def test_any_size_runs_as_a_two_kernel_part_and_a_remainder(ddc, orc, n_wg, extr
     assert np.array_equal(np.concatenate([g[0] for g in got], axis=1), spec)
     assert np.array_equal(np.concatenate([g[1] for g in got], axis=1), voice)
     s.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_call_sizes_on_one_stream_of_samples(ddc, orc, seed):
+    """Seven calls of random sizes (whole two-kernel parts, two-kernel parts with a remainder, and
+    small calls that run as six kernels) on one stream: what a call hands to the next — the NCO
+    phase, the six mixer outputs in front of the next window, the moments, the 48 kHz histories —
+    crosses every pair of plans; rows that end calls on the rails keep the packed hand-over
+    words at their extremes."""
+    rng = np.random.default_rng(4000 + seed)
+    sizes = []
+    for _ in range(7):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            sizes.append(int(rng.integers(1, 4)) * BLK)
+        elif kind == 1:
+            sizes.append(int(rng.integers(1, 3)) * BLK + int(rng.integers(1, 200)) * 1024)
+        else:
+            sizes.append(int(rng.integers(1, 100)) * 1024)
+    total = sum(sizes)
+    nch = 3
+    chans = [rng.integers(-2048, 2048, total).astype(np.int16) for _ in range(nch)]
+    pos = 0
+    for s in sizes:  # the last samples of every call: rails on one channel, alternating rails on another
+        pos += s
+        chans[1][pos - 8:pos] = -2048
+        chans[2][pos - 8:pos:2] = 2047
+        chans[2][pos - 7:pos:2] = -2048
+    phis = [int(rng.integers(1, 1 << 22)), 3 << 20, int(rng.integers(1, 1 << 22))]
+    d = ddc.Ddc(nch)
+    d.tune_many(phis)
+    specs, voices, pos = [], [], 0
+    for s in sizes:
+        sp, vo = d.rx_process(rows_of(ddc, [c[pos:pos + s] for c in chans]), s)
+        specs.append(sp)
+        voices.append(vo)
+        pos += s
+    d.close()
+    spec, voice = np.concatenate(specs, axis=1), np.concatenate(voices, axis=1)
+    for c in range(nch):
+        ws, wv = orc.RxChain(phis[c]).run(chans[c])
+        assert np.array_equal(spec[c], ws) and np.array_equal(voice[c], wv), (c, sizes)
