@@ -352,8 +352,7 @@ __device__ __forceinline__ void group8(const uint2 *tab, uint32_t d0, uint32_t d
     unsigned long long p = accp;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        nco_fetch(tab, (uint32_t)p, e[2 * k], w[2 * k]);
-        nco_fetch(tab, (uint32_t)(p >> 32), e[2 * k + 1], w[2 * k + 1]);
+        nco_fetch_pair(tab, p, e[2 * k], e[2 * k + 1], w[2 * k], w[2 * k + 1]);
         p = pair_add(p, phi2);
     }
     accp = p;
