@@ -164,6 +164,18 @@ struct PolyWalk {
     __device__ __forceinline__ int out14() const { return (int)(uint32_t)(p >> 32) >> 16; }
 };
 
+// tx_mixer + tx_summator + the DAC offset: I * sin14 + Q * cos14 + (8191 << 14) as two multiply-adds.  All four
+// factors sit in upper halves — the tx_cic outputs in bits 63..48 of the walks, the NCO values in bits 31..16 of
+// the angle sums — and v_mad_i32_i16 picks that half of each source by itself (two SDWA multiplies and a
+// three-operand add before).
+__device__ __forceinline__ uint32_t tx_mix(unsigned long long p_i, unsigned long long p_q, int s14x, int c14x)
+{
+    int t, r;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(t) : "v"((uint32_t)(p_i >> 32)), "v"(s14x), "s"(8191 << 14));
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(r) : "v"((uint32_t)(p_q >> 32)), "v"(c14x), "v"(t));
+    return (uint32_t)r;
+}
+
 /*
  * One thread writes one aligned block of 512 DAC samples (1 KB) of one channel:
  * block g (1..n96) is t = 512 (g - 1) + k, k = 0..511.  The interpolated tx_cic
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(256) void ddc_tx_duc(const int16_t *__restrict__ yb
             nco14x_pair(tab, php, s14x, c14x);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                sum[h] = (uint32_t)(__mul24(wi.out14(), s14x[h] >> 16) + __mul24(wq.out14(), c14x[h] >> 16) + (8191 << 14));
+                sum[h] = tx_mix(wi.p, wq.p, s14x[h], c14x[h]);
                 wi.next();
                 wq.next();
             }
